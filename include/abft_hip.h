@@ -1,0 +1,213 @@
+/*
+ * abft_hip.h -- C ABI of the MI355X (gfx950) ABFT sparse-CG engine.
+ *
+ * This is the drop-in boundary for the `-t hip` target of abft-sparse-cg: one
+ * entry point per virtual method of the reference plugin interface
+ * (reference CGContext.h:13-36), plus the few additive calls a device backend
+ * needs (stream hand-over, event drain, shard creation, profiling).  Plain
+ * pointers and sizes only: no C++ types, no torch types.
+ *
+ * Conventions
+ *   - every call returns ABFT_OK (0) or a negative ABFT_ERR_* code; the text of
+ *     the last failure on the calling thread is abft_hip_last_error();
+ *   - handles are opaque and owned by the library until the matching destroy;
+ *   - host arrays passed to *_create_* are copied before the call returns
+ *     (reference cg.cpp:418-422 frees them right after create_matrix);
+ *   - spmv / calc_p / copy are asynchronous on the context's HIP stream;
+ *     dot / calc_xr / map / drain_events synchronise it (reference semantics:
+ *     CGContext.h:27-30 return the scalar by value);
+ *   - nothing here prints or exits: ECC / constraint events are queued on the
+ *     device and handed to the caller by abft_hip_drain_events(), which the
+ *     host-side HIPContext turns into the reference's exact printf lines and
+ *     exit(1) (reference CSR/CPUContext.cpp:175-400).
+ */
+#ifndef ABFT_HIP_H
+#define ABFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABFT_OK 0
+#define ABFT_ERR_INVALID (-1)  /* bad argument / shape mismatch              */
+#define ABFT_ERR_HIP (-2)      /* a HIP runtime call failed                  */
+#define ABFT_ERR_NOMEM (-3)    /* host or device allocation failed           */
+#define ABFT_ERR_RANGE (-4)    /* column index does not fit the ECC layout   */
+#define ABFT_ERR_NODEVICE (-5) /* no usable gfx950 device                    */
+
+/* -m modes: reference CSR/CPUContext.cpp:415-420, COO/CPUContext.cpp:383-388 */
+typedef enum {
+  ABFT_MODE_NONE = 0,
+  ABFT_MODE_CONSTRAINTS = 1,
+  ABFT_MODE_SED = 2,
+  ABFT_MODE_SEC7 = 3,
+  ABFT_MODE_SEC8 = 4,
+  ABFT_MODE_SECDED = 5
+} abft_mode;
+
+/* storage format: cg-csr links CSR/, cg-coo links COO/ (reference Makefile:22-52) */
+typedef enum { ABFT_FMT_CSR = 0, ABFT_FMT_COO = 1 } abft_format;
+
+/* reference CGContext.h:11 */
+typedef enum { ABFT_FLIP_ANY = 0, ABFT_FLIP_VALUE = 1, ABFT_FLIP_INDEX = 2 } abft_flip_kind;
+
+/* One queued event == one printf line of the reference backend. */
+typedef enum {
+  ABFT_EV_SED_DETECTED = 1,     /* "[ECC] error detected at index %d"               fatal */
+  ABFT_EV_CORRECTED_BIT = 2,    /* "[ECC] corrected bit %u at index %d"                   */
+  ABFT_EV_CORRECTED_PARITY = 3, /* "[ECC] corrected overall parity bit at index %d"       */
+  ABFT_EV_DOUBLE_BIT = 4,       /* "[ECC] double-bit error detected"                fatal */
+  ABFT_EV_ROW_SIZE = 5,         /* "row size constraint violated for ..."           fatal */
+  ABFT_EV_ROW_ORDER = 6,        /* "row order constraint violated ..."              fatal */
+  ABFT_EV_COL_SIZE = 7,         /* "column size constraint violated ..."            fatal */
+  ABFT_EV_COL_ORDER = 8         /* "column order constraint violated ..."           fatal */
+} abft_event_kind;
+
+typedef struct {
+  uint32_t kind;  /* abft_event_kind                                             */
+  uint32_t index; /* element index i (or row, for the CSR row events), global    */
+  uint32_t bit;   /* corrected bit for ABFT_EV_CORRECTED_BIT, else 0             */
+  uint32_t fmt;   /* abft_format of the matrix that raised it                    */
+} abft_event;
+
+typedef struct abft_hip_ctx abft_hip_ctx;
+typedef struct abft_hip_matrix abft_hip_matrix;
+typedef struct abft_hip_vector abft_hip_vector;
+
+/* ---- library / context ------------------------------------------------- */
+
+const char *abft_hip_last_error(void);
+int abft_hip_device_count(int *count);
+
+/* Replaces `new HIPContext` (reference CGContext::create, CGContext.cpp:9-25).
+ * Binds the context to `device` and creates its stream and scratch buffers. */
+int abft_hip_init(int device, abft_hip_ctx **ctx);
+int abft_hip_shutdown(abft_hip_ctx *ctx);
+
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream) instead of
+ * the context's own stream; NULL restores the own stream. */
+int abft_hip_set_stream(abft_hip_ctx *ctx, void *hip_stream);
+void *abft_hip_get_stream(abft_hip_ctx *ctx);
+int abft_hip_synchronize(abft_hip_ctx *ctx);
+
+/* ---- matrix ------------------------------------------------------------ */
+
+/* reference CSR/CPUContext.cpp:11-44 (create_matrix + generate_ecc_bits).
+ * columns/rows/values are COO triplets sorted by (row, col), 0-based.
+ * ECC modes need every column < 2^24 (reference CSR/CPUContext.cpp:238). */
+int abft_hip_matrix_create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns,
+                               const uint32_t *rows, const double *values, int N, int nnz,
+                               abft_hip_matrix **mat);
+/* reference COO/CPUContext.cpp:11-36 */
+int abft_hip_matrix_create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns,
+                               const uint32_t *rows, const double *values, int N, int nnz,
+                               abft_hip_matrix **mat);
+/* Row-block shard of a larger matrix (multi-GPU): `nrows` local
+ * rows (row indices local, 0-based), columns index a vector of length `ncols`,
+ * event indices are reported as index_base + local i. */
+int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int mode,
+                                 const uint32_t *columns, const uint32_t *rows,
+                                 const double *values, int nrows, int ncols, int nnz,
+                                 uint32_t index_base, abft_hip_matrix **mat);
+/* reference CSR/CPUContext.cpp:46-52 */
+int abft_hip_matrix_destroy(abft_hip_matrix *mat);
+
+/* Read back the stored (ECC-encoded) arrays in the caller's element order.
+ * CSR: cols[nnz], rowptr[nrows+1], values[nnz].  Any pointer may be NULL. */
+int abft_hip_matrix_read_csr(abft_hip_matrix *mat, uint32_t *cols, uint32_t *rowptr,
+                             double *values);
+/* COO: 16-byte elements {col,row,value} (reference COO/ecc.h:11-16), nnz of them. */
+int abft_hip_matrix_read_coo(abft_hip_matrix *mat, void *elements);
+
+/* reference CSR/CPUContext.cpp:135-159 / COO/CPUContext.cpp:123-140, minus the
+ * rand() draws: the host picks `index` and the bits (so the libc sequence stays
+ * the reference's) and the device XORs them into element `index`.  Bit
+ * numbering is the reference's: CSR 0-63 value, 64-95 column; COO 0-31 col,
+ * 32-63 row, 64-127 value. */
+int abft_hip_inject(abft_hip_matrix *mat, uint32_t index, const int *bits, int nbits);
+
+/* ---- vectors ----------------------------------------------------------- */
+
+/* reference CSR/CPUContext.cpp:54-75: contents are uninitialised */
+int abft_hip_vector_create(abft_hip_ctx *ctx, int N, abft_hip_vector **vec);
+/* A window [offset, offset+N) of `parent` (the local slice of a gathered
+ * vector); does not own memory. */
+int abft_hip_vector_view(abft_hip_vector *parent, int offset, int N, abft_hip_vector **vec);
+int abft_hip_vector_destroy(abft_hip_vector *vec);
+/* map: device -> pinned host staging, returns the host pointer (valid until
+ * unmap); unmap: host staging -> device.  reference CSR/CPUContext.cpp:68-75 */
+int abft_hip_vector_map(abft_hip_vector *vec, double **host);
+int abft_hip_vector_unmap(abft_hip_vector *vec, double *host);
+/* reference CSR/CPUContext.cpp:77-80: copies dst->N doubles */
+int abft_hip_vector_copy(abft_hip_vector *dst, const abft_hip_vector *src);
+void *abft_hip_vector_device_ptr(abft_hip_vector *vec);
+int abft_hip_vector_length(abft_hip_vector *vec);
+
+/* ---- the CG kernels ---------------------------------------------------- */
+
+/* reference CSR/CPUContext.cpp:82-90 */
+int abft_hip_dot(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b,
+                 double *result);
+/* reference CSR/CPUContext.cpp:92-105: x += alpha p; r -= alpha w; returns r.r */
+int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
+                     const abft_hip_vector *p, const abft_hip_vector *w, double alpha,
+                     double *result);
+/* reference CSR/CPUContext.cpp:107-113: p = r + beta p */
+int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r,
+                    double beta);
+/* reference CSR/CPUContext.cpp:115-133 and the five ABFT variants :162-411;
+ * COO/CPUContext.cpp:104-121 and :142-379.  The mode is the matrix's. */
+int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                  abft_hip_vector *result);
+
+/* Shard-local forms for the row-partitioned solver: same kernels, but the
+ * scalar stays on the device (`dev_result` is a device pointer to one double)
+ * so a collective can sum it across ranks before the host reads it. */
+int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b,
+                     double *dev_result);
+int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
+                         const abft_hip_vector *p, const abft_hip_vector *w, double alpha,
+                         double *dev_result);
+
+/* ---- events ------------------------------------------------------------ */
+
+/* Synchronise, then move the queued events to `buf` (at most `cap`), sorted
+ * by (index, kind) and cut after the first fatal one -- the order a
+ * single-threaded reference run prints them in.  *count = events returned,
+ * *fatal = 1 if the last one is fatal (the reference would have exit(1)ed). */
+int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap, int *count, int *fatal);
+/* Number of events queued as of the last synchronising call (no sync). */
+int abft_hip_pending_events(abft_hip_ctx *ctx);
+/* The reference's exact printf line for an event, including the newline. */
+int abft_format_event(const abft_event *ev, char *buf, size_t cap);
+int abft_event_is_fatal(uint32_t kind);
+
+/* ---- measurement ------------------------------------------------------- */
+
+typedef enum {
+  ABFT_K_SPMV = 0,
+  ABFT_K_DOT = 1,
+  ABFT_K_CALC_XR = 2,
+  ABFT_K_CALC_P = 3,
+  ABFT_K_COUNT = 4
+} abft_kernel_id;
+
+/* When enabled, every launch of the four CG kernels is bracketed by HIP
+ * events on the context's stream.  abft_hip_profile_read synchronises and
+ * returns the summed device time (ms) and launch count since the last reset. */
+int abft_hip_profile_enable(abft_hip_ctx *ctx, int on);
+int abft_hip_profile_reset(abft_hip_ctx *ctx);
+int abft_hip_profile_read(abft_hip_ctx *ctx, int kernel, double *total_ms, long *launches);
+
+/* Device streaming-copy bandwidth probe (bytes moved = 2*bytes per rep):
+ * the measured-peak denominator SURVEY 8(d) asks for beside the 8 TB/s spec. */
+int abft_hip_stream_probe(abft_hip_ctx *ctx, size_t bytes, int reps, double *gbps_copy,
+                          double *gbps_read);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABFT_HIP_H */
