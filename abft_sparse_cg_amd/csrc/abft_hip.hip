@@ -1,0 +1,728 @@
+// abft_hip.hip -- implementation of the C ABI in include/abft_hip.h: handle
+// management, host-side matrix preparation (row pointers, row blocks, COO
+// grouping), HIP stream plumbing, event drain.  The device code is in
+// kernels.hip.  Nothing here prints or exits; nothing here falls back to a CPU
+// path -- a failing HIP call surfaces as ABFT_ERR_HIP.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "abft_internal.h"
+
+// ------------------------------------------------------------------ errors --
+
+static thread_local char g_err[512] = "";
+
+static int set_err(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCHK(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return set_err(ABFT_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                              \
+  } while (0)
+
+extern "C" const char *abft_hip_last_error(void) { return g_err; }
+
+// ----------------------------------------------------------------- handles --
+
+struct HostSlot {
+  double value;
+  uint32_t evcount;
+  uint32_t pad;
+};
+
+struct ProfSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  double total_ms = 0.0;
+  long launches = 0;
+};
+
+struct abft_hip_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  double *partials = nullptr;  // ABFT_MAX_PARTIALS doubles
+  HostSlot *host_slot = nullptr;      // pinned, device-visible
+  HostSlot *host_slot_dev = nullptr;  // its device alias
+  EventRing ring{};                   // device memory
+  int *bits_dev = nullptr;            // scratch for inject (32 ints)
+  bool prof = false;
+  ProfSlot prof_k[ABFT_K_COUNT];
+  std::vector<hipEvent_t> ev_pool;
+};
+
+struct abft_hip_matrix {
+  abft_hip_ctx *ctx = nullptr;
+  int fmt = 0, mode = 0;
+  CsrDev csr{};
+  CooDev coo{};
+  std::vector<void *> allocs;
+};
+
+struct abft_hip_vector {
+  abft_hip_ctx *ctx = nullptr;
+  double *d = nullptr;
+  int n = 0;
+  bool owns = true;
+  double *host = nullptr;  // pinned staging for map/unmap
+};
+
+static constexpr uint32_t EVENT_CAP = 1u << 16;
+
+static int bind(abft_hip_ctx *ctx) {
+  if (!ctx) return set_err(ABFT_ERR_INVALID, "null context");
+  HIPCHK(hipSetDevice(ctx->device));
+  return ABFT_OK;
+}
+
+// ---- profiling brackets ----
+
+struct KernelTimer {
+  abft_hip_ctx *ctx;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  KernelTimer(abft_hip_ctx *c, int k) : ctx(c), id(k) {
+    if (!ctx->prof) return;
+    a = take();
+    b = take();
+    if (a && b) (void)hipEventRecord(a, ctx->stream);
+  }
+  ~KernelTimer() {
+    if (!ctx->prof || !a || !b) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof_k[id].pending.emplace_back(a, b);
+    if (ctx->prof_k[id].pending.size() >= 4096) fold(ctx, id);
+  }
+  hipEvent_t take() {
+    if (!ctx->ev_pool.empty()) {
+      hipEvent_t e = ctx->ev_pool.back();
+      ctx->ev_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+  static void fold(abft_hip_ctx *ctx, int id) {
+    ProfSlot &p = ctx->prof_k[id];
+    for (auto &pr : p.pending) {
+      float ms = 0.f;
+      if (hipEventSynchronize(pr.second) == hipSuccess &&
+          hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        p.total_ms += ms;
+        p.launches++;
+      }
+      ctx->ev_pool.push_back(pr.first);
+      ctx->ev_pool.push_back(pr.second);
+    }
+    p.pending.clear();
+  }
+};
+
+// ------------------------------------------------------------------ context --
+
+extern "C" int abft_hip_device_count(int *count) {
+  if (!count) return set_err(ABFT_ERR_INVALID, "null count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    return set_err(ABFT_ERR_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  }
+  *count = n;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
+  if (!out) return set_err(ABFT_ERR_INVALID, "null out");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return set_err(ABFT_ERR_NODEVICE, "no HIP device visible (this engine has no CPU fallback)");
+  if (device < 0 || device >= n) return set_err(ABFT_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return set_err(ABFT_ERR_NODEVICE, "device %d is %s; this library carries gfx950 code only", device,
+                   prop.gcnArchName);
+  abft_hip_ctx *ctx = new (std::nothrow) abft_hip_ctx();
+  if (!ctx) return set_err(ABFT_ERR_NOMEM, "context allocation failed");
+  ctx->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  ctx->stream = ctx->own_stream;
+  HIPCHK(hipMalloc((void **)&ctx->partials, ABFT_MAX_PARTIALS * sizeof(double)));
+  HIPCHK(hipHostMalloc((void **)&ctx->host_slot, sizeof(HostSlot), hipHostMallocMapped));
+  memset(ctx->host_slot, 0, sizeof(HostSlot));
+  HIPCHK(hipHostGetDevicePointer((void **)&ctx->host_slot_dev, ctx->host_slot, 0));
+  HIPCHK(hipMalloc((void **)&ctx->ring.buf, EVENT_CAP * sizeof(abft_event)));
+  HIPCHK(hipMalloc((void **)&ctx->ring.count, sizeof(uint32_t)));
+  HIPCHK(hipMemset(ctx->ring.count, 0, sizeof(uint32_t)));
+  ctx->ring.cap = EVENT_CAP;
+  HIPCHK(hipMalloc((void **)&ctx->bits_dev, 32 * sizeof(int)));
+  *out = ctx;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
+  if (!ctx) return ABFT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (int k = 0; k < ABFT_K_COUNT; k++) KernelTimer::fold(ctx, k);
+  for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+  (void)hipFree(ctx->partials);
+  (void)hipHostFree(ctx->host_slot);
+  (void)hipFree(ctx->ring.buf);
+  (void)hipFree(ctx->ring.count);
+  (void)hipFree(ctx->bits_dev);
+  (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_set_stream(abft_hip_ctx *ctx, void *hip_stream) {
+  if (int rc = bind(ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return ABFT_OK;
+}
+
+extern "C" void *abft_hip_get_stream(abft_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int abft_hip_synchronize(abft_hip_ctx *ctx) {
+  if (int rc = bind(ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return ABFT_OK;
+}
+
+// ------------------------------------------------------------------- matrix --
+
+template <typename T>
+static int dev_upload(abft_hip_matrix *m, T **dst, const T *src, size_t count, size_t alloc_count) {
+  T *p = nullptr;
+  if (alloc_count < count) alloc_count = count;
+  if (alloc_count == 0) alloc_count = 1;
+  if (hipMalloc((void **)&p, alloc_count * sizeof(T)) != hipSuccess)
+    return set_err(ABFT_ERR_NOMEM, "hipMalloc of %zu bytes failed", alloc_count * sizeof(T));
+  m->allocs.push_back(p);
+  if (alloc_count > count)
+    HIPCHK(hipMemsetAsync(p + count, 0, (alloc_count - count) * sizeof(T), m->ctx->stream));
+  if (count) HIPCHK(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, m->ctx->stream));
+  *dst = p;
+  return ABFT_OK;
+}
+
+static void matrix_free(abft_hip_matrix *m) {
+  if (!m) return;
+  for (void *p : m->allocs) (void)hipFree(p);
+  delete m;
+}
+
+// Cut [0, n) into blocks of whole segments whose elements fit one LDS tile.
+// `align2`: the tile starts at the even element at or below the block's first
+// element (CSR pair loads), so that one counts against the capacity too.
+static void cut_blocks(const uint32_t *ptr, uint32_t n, uint32_t tile, bool align2,
+                       std::vector<uint32_t> &blk) {
+  const uint32_t max_segments = 4 * ABFT_BLOCK;
+  blk.clear();
+  blk.push_back(0);
+  uint32_t s = 0;
+  while (s < n) {
+    const uint32_t base = align2 ? (ptr[s] & ~1u) : ptr[s];
+    uint32_t e = s;
+    while (e < n && e - s < max_segments && ptr[e + 1] >= ptr[e] && ptr[e + 1] - base <= tile) e++;
+    if (e == s) e = s + 1;  // a single segment longer than a tile: walked tile by tile
+    blk.push_back(e);
+    s = e;
+  }
+}
+
+static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, const uint32_t *rows,
+                      const double *values, int n_out, int n_in, int nnz, uint32_t index_base,
+                      abft_hip_matrix **out) {
+  // validate: a bad index must fail here, loudly, not fault a kernel later
+  for (int i = 0; i < nnz; i++) {
+    if (rows[i] >= (uint32_t)n_out)
+      return set_err(ABFT_ERR_INVALID, "row index %u at element %d is outside [0,%d)", rows[i], i, n_out);
+    if (i && rows[i] < rows[i - 1])
+      return set_err(ABFT_ERR_INVALID, "elements are not sorted by row at element %d", i);
+    if (mode >= ABFT_MODE_SED && columns[i] > ABFT_COLMASK_HOST)
+      return set_err(ABFT_ERR_RANGE, "column %u at element %d needs more than 24 bits: ECC modes keep "
+                     "their check bits in the column's top byte", columns[i], i);
+  }
+  abft_hip_matrix *m = new (std::nothrow) abft_hip_matrix();
+  if (!m) return set_err(ABFT_ERR_NOMEM, "matrix allocation failed");
+  m->ctx = ctx; m->fmt = ABFT_FMT_CSR; m->mode = mode;
+  // row pointers exactly as the reference builds them (CSR/CPUContext.cpp:24-41);
+  // trailing empty rows get nnz (the reference leaves them uninitialised)
+  std::vector<uint32_t> rowptr((size_t)n_out + 1);
+  uint32_t next = 0;
+  for (int i = 0; i < nnz; i++)
+    while (next <= rows[i]) rowptr[next++] = (uint32_t)i;
+  while (next <= (uint32_t)n_out) rowptr[next++] = (uint32_t)nnz;
+  std::vector<uint32_t> blk;
+  cut_blocks(rowptr.data(), (uint32_t)n_out, ABFT_CSR_TILE, true, blk);
+
+  CsrDev &A = m->csr;
+  A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
+  A.nblk = (uint32_t)blk.size() - 1;
+  const size_t padded = ((size_t)nnz + 3) & ~(size_t)1;  // even, >= nnz + 2
+  int rc;
+  uint32_t *d_rowptr = nullptr, *d_blk = nullptr;
+  if ((rc = dev_upload(m, &A.cols, columns, (size_t)nnz, padded)) ||
+      (rc = dev_upload(m, &A.vals, values, (size_t)nnz, padded)) ||
+      (rc = dev_upload(m, &d_rowptr, rowptr.data(), rowptr.size(), rowptr.size())) ||
+      (rc = dev_upload(m, &d_blk, blk.data(), blk.size(), blk.size()))) {
+    matrix_free(m);
+    return rc;
+  }
+  A.rowptr = d_rowptr;
+  A.blk_row = d_blk;
+  hipError_t e = launch_encode_csr(mode, A.cols, A.vals, A.nnz, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host arrays may be freed on return
+  if (e != hipSuccess) {
+    matrix_free(m);
+    return set_err(ABFT_ERR_HIP, "CSR upload/encode failed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return ABFT_OK;
+}
+
+static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, const uint32_t *rows,
+                      const double *values, int n_out, int n_in, int nnz, uint32_t index_base,
+                      abft_hip_matrix **out) {
+  for (int i = 0; i < nnz; i++) {
+    if (columns[i] >= (uint32_t)n_out)
+      return set_err(ABFT_ERR_INVALID, "column index %u at element %d is outside [0,%d)", columns[i], i, n_out);
+    if (mode >= ABFT_MODE_SED && columns[i] > ABFT_COLMASK_HOST)
+      return set_err(ABFT_ERR_RANGE, "column %u at element %d needs more than 24 bits", columns[i], i);
+  }
+  abft_hip_matrix *m = new (std::nothrow) abft_hip_matrix();
+  if (!m) return set_err(ABFT_ERR_NOMEM, "matrix allocation failed");
+  m->ctx = ctx; m->fmt = ABFT_FMT_COO; m->mode = mode;
+  // Group by output index (col), stable in the caller's order: result[col] is
+  // then summed in the order the reference's serial scatter adds into it
+  // (COO/CPUContext.cpp:111-120).
+  std::vector<uint32_t> grp((size_t)n_out + 1, 0);
+  for (int i = 0; i < nnz; i++) grp[columns[i] + 1]++;
+  for (int c = 0; c < n_out; c++) grp[c + 1] += grp[c];
+  std::vector<uint32_t> fill(grp.begin(), grp.end() - 1);
+  std::vector<uint32_t> orig((size_t)std::max(nnz, 1)), pos((size_t)std::max(nnz, 1));
+  struct El { uint32_t col, row; double value; };
+  std::vector<El> elems((size_t)std::max(nnz, 1));
+  for (int i = 0; i < nnz; i++) {
+    const uint32_t p = fill[columns[i]]++;
+    elems[p] = El{columns[i], rows[i], values[i]};
+    orig[p] = (uint32_t)i;
+    pos[i] = p;
+  }
+  std::vector<uint32_t> blk;
+  cut_blocks(grp.data(), (uint32_t)n_out, ABFT_COO_TILE, false, blk);
+
+  CooDev &A = m->coo;
+  A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
+  A.nblk = (uint32_t)blk.size() - 1;
+  int rc;
+  uint32_t *d_grp = nullptr, *d_blk = nullptr, *d_orig = nullptr, *d_pos = nullptr;
+  uint4 *d_el = nullptr;
+  if ((rc = dev_upload(m, &d_el, reinterpret_cast<const uint4 *>(elems.data()), (size_t)nnz, (size_t)nnz + 1)) ||
+      (rc = dev_upload(m, &d_grp, grp.data(), grp.size(), grp.size())) ||
+      (rc = dev_upload(m, &d_blk, blk.data(), blk.size(), blk.size())) ||
+      (rc = dev_upload(m, &d_orig, orig.data(), (size_t)nnz, (size_t)nnz)) ||
+      (rc = dev_upload(m, &d_pos, pos.data(), (size_t)nnz, (size_t)nnz))) {
+    matrix_free(m);
+    return rc;
+  }
+  A.elems = d_el; A.grp_ptr = d_grp; A.blk_grp = d_blk; A.orig_index = d_orig; A.pos_of_orig = d_pos;
+  hipError_t e = launch_encode_coo(mode, A.elems, A.nnz, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    matrix_free(m);
+    return set_err(ABFT_ERR_HIP, "COO upload/encode failed: %s", hipGetErrorString(e));
+  }
+  *out = m;
+  return ABFT_OK;
+}
+
+static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *columns,
+                      const uint32_t *rows, const double *values, int n_out, int n_in, int nnz,
+                      uint32_t index_base, abft_hip_matrix **out) {
+  if (int rc = bind(ctx)) return rc;
+  if (!out) return set_err(ABFT_ERR_INVALID, "null out");
+  *out = nullptr;
+  if (mode < ABFT_MODE_NONE || mode > ABFT_MODE_SECDED) return set_err(ABFT_ERR_INVALID, "unknown mode %d", mode);
+  if (n_out < 0 || n_in < 0 || nnz < 0) return set_err(ABFT_ERR_INVALID, "negative size");
+  if (nnz && (!columns || !rows || !values)) return set_err(ABFT_ERR_INVALID, "null input array");
+  if (format == ABFT_FMT_CSR) return create_csr(ctx, mode, columns, rows, values, n_out, n_in, nnz, index_base, out);
+  if (format == ABFT_FMT_COO) return create_coo(ctx, mode, columns, rows, values, n_out, n_in, nnz, index_base, out);
+  return set_err(ABFT_ERR_INVALID, "unknown format %d", format);
+}
+
+extern "C" int abft_hip_matrix_create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns,
+                                          const uint32_t *rows, const double *values, int N, int nnz,
+                                          abft_hip_matrix **mat) {
+  return create_any(ctx, ABFT_FMT_CSR, mode, columns, rows, values, N, N, nnz, 0, mat);
+}
+
+extern "C" int abft_hip_matrix_create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns,
+                                          const uint32_t *rows, const double *values, int N, int nnz,
+                                          abft_hip_matrix **mat) {
+  return create_any(ctx, ABFT_FMT_COO, mode, columns, rows, values, N, N, nnz, 0, mat);
+}
+
+extern "C" int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int mode,
+                                            const uint32_t *columns, const uint32_t *rows,
+                                            const double *values, int n_out, int n_in, int nnz,
+                                            uint32_t index_base, abft_hip_matrix **mat) {
+  return create_any(ctx, format, mode, columns, rows, values, n_out, n_in, nnz, index_base, mat);
+}
+
+extern "C" int abft_hip_matrix_destroy(abft_hip_matrix *mat) {
+  if (!mat) return ABFT_OK;
+  if (int rc = bind(mat->ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(mat->ctx->stream));
+  matrix_free(mat);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_matrix_read_csr(abft_hip_matrix *mat, uint32_t *cols, uint32_t *rowptr,
+                                        double *values) {
+  if (!mat || mat->fmt != ABFT_FMT_CSR) return set_err(ABFT_ERR_INVALID, "not a CSR matrix");
+  if (int rc = bind(mat->ctx)) return rc;
+  hipStream_t s = mat->ctx->stream;
+  const CsrDev &A = mat->csr;
+  if (cols && A.nnz) HIPCHK(hipMemcpyAsync(cols, A.cols, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
+  if (values && A.nnz) HIPCHK(hipMemcpyAsync(values, A.vals, (size_t)A.nnz * 8, hipMemcpyDeviceToHost, s));
+  if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, A.rowptr, ((size_t)A.n_out + 1) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_matrix_read_coo(abft_hip_matrix *mat, void *elements) {
+  if (!mat || mat->fmt != ABFT_FMT_COO) return set_err(ABFT_ERR_INVALID, "not a COO matrix");
+  if (int rc = bind(mat->ctx)) return rc;
+  const CooDev &A = mat->coo;
+  if (!elements || !A.nnz) return ABFT_OK;
+  std::vector<uint4> stored(A.nnz);
+  std::vector<uint32_t> orig(A.nnz);
+  hipStream_t s = mat->ctx->stream;
+  HIPCHK(hipMemcpyAsync(stored.data(), A.elems, (size_t)A.nnz * 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(orig.data(), A.orig_index, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  uint4 *dst = static_cast<uint4 *>(elements);
+  for (uint32_t p = 0; p < A.nnz; p++) dst[orig[p]] = stored[p];
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_inject(abft_hip_matrix *mat, uint32_t index, const int *bits, int nbits) {
+  if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
+  if (int rc = bind(mat->ctx)) return rc;
+  const uint32_t nnz = mat->fmt == ABFT_FMT_CSR ? mat->csr.nnz : mat->coo.nnz;
+  const int width = mat->fmt == ABFT_FMT_CSR ? 96 : 128;
+  if (index >= nnz) return set_err(ABFT_ERR_INVALID, "element index %u outside [0,%u)", index, nnz);
+  if (nbits < 0 || nbits > 32 || (nbits && !bits)) return set_err(ABFT_ERR_INVALID, "bad bit list");
+  for (int k = 0; k < nbits; k++)
+    if (bits[k] < 0 || bits[k] >= width) return set_err(ABFT_ERR_INVALID, "bit %d outside [0,%d)", bits[k], width);
+  if (!nbits) return ABFT_OK;
+  abft_hip_ctx *ctx = mat->ctx;
+  HIPCHK(hipMemcpyAsync(ctx->bits_dev, bits, (size_t)nbits * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  hipError_t e = mat->fmt == ABFT_FMT_CSR
+                     ? launch_inject_csr(mat->csr.vals, mat->csr.cols, index, ctx->bits_dev, nbits, ctx->stream)
+                     : launch_inject_coo(mat->coo.elems, mat->coo.pos_of_orig, index, ctx->bits_dev, nbits, ctx->stream);
+  HIPCHK(e);
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // `bits` is the caller's
+  return ABFT_OK;
+}
+
+// ------------------------------------------------------------------ vectors --
+
+extern "C" int abft_hip_vector_create(abft_hip_ctx *ctx, int N, abft_hip_vector **vec) {
+  if (int rc = bind(ctx)) return rc;
+  if (!vec || N < 0) return set_err(ABFT_ERR_INVALID, "bad vector arguments");
+  abft_hip_vector *v = new (std::nothrow) abft_hip_vector();
+  if (!v) return set_err(ABFT_ERR_NOMEM, "vector allocation failed");
+  v->ctx = ctx; v->n = N; v->owns = true;
+  if (hipMalloc((void **)&v->d, ((size_t)N + 2) * sizeof(double)) != hipSuccess) {
+    delete v;
+    return set_err(ABFT_ERR_NOMEM, "hipMalloc of %zu bytes failed", ((size_t)N + 2) * sizeof(double));
+  }
+  *vec = v;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_vector_view(abft_hip_vector *parent, int offset, int N, abft_hip_vector **vec) {
+  if (!parent || !vec || offset < 0 || N < 0 || (long)offset + N > parent->n)
+    return set_err(ABFT_ERR_INVALID, "view [%d,%d) outside parent of length %d", offset, offset + N,
+                   parent ? parent->n : -1);
+  abft_hip_vector *v = new (std::nothrow) abft_hip_vector();
+  if (!v) return set_err(ABFT_ERR_NOMEM, "vector allocation failed");
+  v->ctx = parent->ctx; v->d = parent->d + offset; v->n = N; v->owns = false;
+  *vec = v;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_vector_destroy(abft_hip_vector *vec) {
+  if (!vec) return ABFT_OK;
+  if (int rc = bind(vec->ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(vec->ctx->stream));
+  if (vec->host) (void)hipHostFree(vec->host);
+  if (vec->owns) (void)hipFree(vec->d);
+  delete vec;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_vector_map(abft_hip_vector *vec, double **host) {
+  if (!vec || !host) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (int rc = bind(vec->ctx)) return rc;
+  if (!vec->host) HIPCHK(hipHostMalloc((void **)&vec->host, ((size_t)vec->n + 1) * sizeof(double), hipHostMallocDefault));
+  if (vec->n) HIPCHK(hipMemcpyAsync(vec->host, vec->d, (size_t)vec->n * sizeof(double), hipMemcpyDeviceToHost, vec->ctx->stream));
+  HIPCHK(hipStreamSynchronize(vec->ctx->stream));
+  *host = vec->host;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_vector_unmap(abft_hip_vector *vec, double *host) {
+  if (!vec || !host) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (int rc = bind(vec->ctx)) return rc;
+  if (vec->n) HIPCHK(hipMemcpyAsync(vec->d, host, (size_t)vec->n * sizeof(double), hipMemcpyHostToDevice, vec->ctx->stream));
+  if (host != vec->host) HIPCHK(hipStreamSynchronize(vec->ctx->stream));  // caller's buffer: done with it on return
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_vector_copy(abft_hip_vector *dst, const abft_hip_vector *src) {
+  if (!dst || !src) return set_err(ABFT_ERR_INVALID, "null vector");
+  if (src->n < dst->n) return set_err(ABFT_ERR_INVALID, "copy of %d elements from a vector of %d", dst->n, src->n);
+  if (int rc = bind(dst->ctx)) return rc;
+  if (dst->n) HIPCHK(hipMemcpyAsync(dst->d, src->d, (size_t)dst->n * sizeof(double), hipMemcpyDeviceToDevice, dst->ctx->stream));
+  return ABFT_OK;
+}
+
+extern "C" void *abft_hip_vector_device_ptr(abft_hip_vector *vec) { return vec ? vec->d : nullptr; }
+extern "C" int abft_hip_vector_length(abft_hip_vector *vec) { return vec ? vec->n : -1; }
+
+// --------------------------------------------------------------- CG kernels --
+
+static int scalar_to_host(abft_hip_ctx *ctx, int nparts, double *result) {
+  HIPCHK(launch_finalize(ctx->partials, nparts, nullptr, &ctx->host_slot_dev->value, ctx->ring.count,
+                         &ctx->host_slot_dev->evcount, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  *result = ctx->host_slot->value;
+  return ABFT_OK;
+}
+
+static int check_same(const abft_hip_vector *a, const abft_hip_vector *b, const char *what) {
+  if (!a || !b) return set_err(ABFT_ERR_INVALID, "%s: null vector", what);
+  if (a->n != b->n) return set_err(ABFT_ERR_INVALID, "%s: lengths differ (%d vs %d)", what, a->n, b->n);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_dot(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b, double *result) {
+  if (int rc = bind(ctx)) return rc;
+  if (int rc = check_same(a, b, "dot")) return rc;
+  if (!result) return set_err(ABFT_ERR_INVALID, "null result");
+  {
+    KernelTimer t(ctx, ABFT_K_DOT);
+    HIPCHK(launch_dot(a->d, b->d, a->n, ctx->partials, ctx->stream));
+  }
+  return scalar_to_host(ctx, reduce_blocks(a->n), result);
+}
+
+extern "C" int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b, double *dev_result) {
+  if (int rc = bind(ctx)) return rc;
+  if (int rc = check_same(a, b, "dot")) return rc;
+  if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
+  {
+    KernelTimer t(ctx, ABFT_K_DOT);
+    HIPCHK(launch_dot(a->d, b->d, a->n, ctx->partials, ctx->stream));
+  }
+  HIPCHK(launch_finalize(ctx->partials, reduce_blocks(a->n), dev_result, nullptr, ctx->ring.count,
+                         &ctx->host_slot_dev->evcount, ctx->stream));
+  return ABFT_OK;
+}
+
+static int calc_xr_launch(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r, const abft_hip_vector *p,
+                          const abft_hip_vector *w, double alpha) {
+  if (int rc = check_same(x, r, "calc_xr")) return rc;
+  if (int rc = check_same(x, p, "calc_xr")) return rc;
+  if (int rc = check_same(x, w, "calc_xr")) return rc;
+  KernelTimer t(ctx, ABFT_K_CALC_XR);
+  HIPCHK(launch_calc_xr(x->d, r->d, p->d, w->d, alpha, x->n, ctx->partials, ctx->stream));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r, const abft_hip_vector *p,
+                                const abft_hip_vector *w, double alpha, double *result) {
+  if (int rc = bind(ctx)) return rc;
+  if (!result) return set_err(ABFT_ERR_INVALID, "null result");
+  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha)) return rc;
+  return scalar_to_host(ctx, reduce_blocks(x->n), result);
+}
+
+extern "C" int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
+                                    const abft_hip_vector *p, const abft_hip_vector *w, double alpha,
+                                    double *dev_result) {
+  if (int rc = bind(ctx)) return rc;
+  if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
+  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha)) return rc;
+  HIPCHK(launch_finalize(ctx->partials, reduce_blocks(x->n), dev_result, nullptr, ctx->ring.count,
+                         &ctx->host_slot_dev->evcount, ctx->stream));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r, double beta) {
+  if (int rc = bind(ctx)) return rc;
+  if (int rc = check_same(p, r, "calc_p")) return rc;
+  KernelTimer t(ctx, ABFT_K_CALC_P);
+  HIPCHK(launch_calc_p(p->d, r->d, beta, p->n, ctx->stream));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                             abft_hip_vector *result) {
+  if (int rc = bind(ctx)) return rc;
+  if (!mat || !vec || !result) return set_err(ABFT_ERR_INVALID, "spmv: null argument");
+  const uint32_t n_out = mat->fmt == ABFT_FMT_CSR ? mat->csr.n_out : mat->coo.n_out;
+  const uint32_t n_in = mat->fmt == ABFT_FMT_CSR ? mat->csr.n_in : mat->coo.n_in;
+  // the kernels index vec with [0,n_in) and result with [0,n_out): check here, on the host
+  if ((uint32_t)vec->n < n_in || (uint32_t)result->n < n_out)
+    return set_err(ABFT_ERR_INVALID, "spmv: vectors (%d in, %d out) shorter than the matrix (%u in, %u out)",
+                   vec->n, result->n, n_in, n_out);
+  if (vec->d == result->d) return set_err(ABFT_ERR_INVALID, "spmv: input and output alias");
+  KernelTimer t(ctx, ABFT_K_SPMV);
+  if (mat->fmt == ABFT_FMT_CSR)
+    HIPCHK(launch_spmv_csr(mat->mode, mat->csr, vec->d, result->d, ctx->ring, ctx->stream));
+  else
+    HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, ctx->stream));
+  return ABFT_OK;
+}
+
+// ------------------------------------------------------------------- events --
+
+extern "C" int abft_event_is_fatal(uint32_t kind) {
+  return kind == ABFT_EV_SED_DETECTED || kind == ABFT_EV_DOUBLE_BIT || kind >= ABFT_EV_ROW_SIZE;
+}
+
+extern "C" int abft_format_event(const abft_event *ev, char *buf, size_t cap) {
+  if (!ev || !buf) return -1;
+  const bool coo = ev->fmt == ABFT_FMT_COO;
+  const int i = (int)ev->index;
+  switch (ev->kind) {
+    case ABFT_EV_SED_DETECTED: return snprintf(buf, cap, "[ECC] error detected at index %d\n", i);
+    case ABFT_EV_CORRECTED_BIT: return snprintf(buf, cap, "[ECC] corrected bit %u at index %d\n", ev->bit, i);
+    case ABFT_EV_CORRECTED_PARITY: return snprintf(buf, cap, "[ECC] corrected overall parity bit at index %d\n", i);
+    case ABFT_EV_DOUBLE_BIT: return snprintf(buf, cap, "[ECC] double-bit error detected\n");
+    case ABFT_EV_ROW_SIZE:
+      return snprintf(buf, cap, coo ? "row size constraint violated for index %d\n"
+                                    : "row size constraint violated for row %d\n", i);
+    case ABFT_EV_ROW_ORDER:
+      return snprintf(buf, cap, coo ? "row index order violated at index %d\n"
+                                    : "row order constraint violated for row%d\n", i);
+    case ABFT_EV_COL_SIZE:
+      return snprintf(buf, cap, coo ? "column size constraint violated for index %d\n"
+                                    : "column size constraint violated at index %d\n", i);
+    case ABFT_EV_COL_ORDER:
+      return snprintf(buf, cap, coo ? "column index order violated at index %d\n"
+                                    : "column order constraint violated at index %d\n", i);
+    default: return snprintf(buf, cap, "unknown event %u\n", ev->kind);
+  }
+}
+
+extern "C" int abft_hip_pending_events(abft_hip_ctx *ctx) { return ctx ? (int)ctx->host_slot->evcount : 0; }
+
+extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap, int *count, int *fatal) {
+  if (int rc = bind(ctx)) return rc;
+  if (!count || cap < 0 || (cap && !buf)) return set_err(ABFT_ERR_INVALID, "bad drain arguments");
+  *count = 0;
+  if (fatal) *fatal = 0;
+  uint32_t n = 0;
+  HIPCHK(hipMemcpyAsync(&n, ctx->ring.count, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (n == 0) { ctx->host_slot->evcount = 0; return ABFT_OK; }
+  if (n > ctx->ring.cap) n = ctx->ring.cap;
+  std::vector<abft_event> ev(n);
+  HIPCHK(hipMemcpyAsync(ev.data(), ctx->ring.buf, (size_t)n * sizeof(abft_event), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->ring.count, 0, sizeof(uint32_t), ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->host_slot->evcount = 0;
+  std::sort(ev.begin(), ev.end(), [](const abft_event &a, const abft_event &b) {
+    return a.index != b.index ? a.index < b.index : a.kind < b.kind;
+  });
+  int out = 0;
+  for (uint32_t i = 0; i < n && out < cap; i++) {
+    buf[out++] = ev[i];
+    if (abft_event_is_fatal(ev[i].kind)) { if (fatal) *fatal = 1; break; }
+  }
+  *count = out;
+  return ABFT_OK;
+}
+
+// -------------------------------------------------------------- measurement --
+
+extern "C" int abft_hip_profile_enable(abft_hip_ctx *ctx, int on) {
+  if (int rc = bind(ctx)) return rc;
+  ctx->prof = on != 0;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_profile_reset(abft_hip_ctx *ctx) {
+  if (int rc = bind(ctx)) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < ABFT_K_COUNT; k++) {
+    KernelTimer::fold(ctx, k);
+    ctx->prof_k[k].total_ms = 0.0;
+    ctx->prof_k[k].launches = 0;
+  }
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_profile_read(abft_hip_ctx *ctx, int kernel, double *total_ms, long *launches) {
+  if (int rc = bind(ctx)) return rc;
+  if (kernel < 0 || kernel >= ABFT_K_COUNT) return set_err(ABFT_ERR_INVALID, "unknown kernel id %d", kernel);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  KernelTimer::fold(ctx, kernel);
+  if (total_ms) *total_ms = ctx->prof_k[kernel].total_ms;
+  if (launches) *launches = ctx->prof_k[kernel].launches;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_stream_probe(abft_hip_ctx *ctx, size_t bytes, int reps, double *gbps_copy, double *gbps_read) {
+  if (int rc = bind(ctx)) return rc;
+  if (bytes < 1024 || reps < 1) return set_err(ABFT_ERR_INVALID, "bad probe arguments");
+  bytes &= ~(size_t)15;
+  double *a = nullptr, *b = nullptr;
+  if (hipMalloc((void **)&a, bytes) != hipSuccess || hipMalloc((void **)&b, bytes) != hipSuccess) {
+    (void)hipFree(a);
+    return set_err(ABFT_ERR_NOMEM, "probe buffers (2 x %zu bytes) do not fit", bytes);
+  }
+  hipEvent_t e0, e1, e2;
+  HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2));
+  hipStream_t s = ctx->stream;
+  HIPCHK(hipMemsetAsync(a, 0x11, bytes, s));
+  HIPCHK(launch_stream_copy(b, a, bytes / 8, s));
+  HIPCHK(launch_stream_read(a, bytes / 8, ctx->partials, s));
+  HIPCHK(hipEventRecord(e0, s));
+  for (int i = 0; i < reps; i++) HIPCHK(launch_stream_copy(b, a, bytes / 8, s));
+  HIPCHK(hipEventRecord(e1, s));
+  for (int i = 0; i < reps; i++) HIPCHK(launch_stream_read(a, bytes / 8, ctx->partials, s));
+  HIPCHK(hipEventRecord(e2, s));
+  HIPCHK(hipEventSynchronize(e2));
+  float ms_c = 0.f, ms_r = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms_c, e0, e1));
+  HIPCHK(hipEventElapsedTime(&ms_r, e1, e2));
+  if (gbps_copy) *gbps_copy = 2.0 * (double)bytes * reps / (ms_c * 1e-3) / 1e9;
+  if (gbps_read) *gbps_read = (double)bytes * reps / (ms_r * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+  (void)hipFree(a); (void)hipFree(b);
+  return ABFT_OK;
+}

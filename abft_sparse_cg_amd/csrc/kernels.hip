@@ -1,0 +1,656 @@
+// kernels.hip -- hand-written CDNA4 (gfx950) kernels of the ABFT sparse-CG hot
+// path.  Everything here is HBM-bound integer/fp64 work: no MFMA; the levers
+// are coalesced streaming of cols/vals, LDS-staged per-row partial products,
+// XCD-aware tile order so each XCD's L2 keeps its own window of x, 64-lane
+// wave reductions, and the ECC check folded into the load path.
+//
+// Numerics: compiled with -ffp-contract=off.  SpMV sums every row in ascending
+// element order with separate multiply and add, so y is bit-identical to the
+// reference CPUContext (CSR/CPUContext.cpp:115-133); calc_xr/calc_p are
+// bit-identical element-wise; only the two reductions (tree order) differ from
+// the reference's serial sums, in the last bits.
+#include "abft_internal.h"
+#include "ecc_device.h"
+
+// native vector types (what __builtin_nontemporal_load accepts)
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ helpers --
+
+// Hardware deals consecutive workgroup ids round-robin over the 8 XCDs
+// (MI355X_MICROARCH: blocks b and b+8 share one).  Give each XCD a contiguous
+// range of tiles so the x-window its blocks gather from stays in that XCD's L2
+// (speed only; the map is a bijection for every nblk).
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nblk) {
+  const uint32_t xcd = b & 7u, q = nblk >> 3, r = nblk & 7u;
+  const uint32_t first = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  return first + (b >> 3);
+}
+
+__device__ __forceinline__ void push_event(const EventRing &ev, uint32_t kind, uint32_t index,
+                                           uint32_t bit, uint32_t fmt) {
+  uint32_t slot = atomicAdd(ev.count, 1u);
+  if (slot < ev.cap) {
+    abft_event e;
+    e.kind = kind; e.index = index; e.bit = bit; e.fmt = fmt;
+    ev.buf[slot] = e;
+  }
+}
+
+__device__ __forceinline__ double gather_x(const double *__restrict__ x, uint32_t idx, uint32_t n) {
+  return idx < n ? x[idx] : 0.0;  // a corrupted index must never fault the GPU
+}
+
+__device__ __forceinline__ double as_double(uint32_t lo, uint32_t hi) {
+  return __hiloint2double((int)hi, (int)lo);
+}
+
+// Cold path of the ECC modes: the element failed its check.  Repairs `w` in
+// place when the mode can and queues the event.  Returns 1 = repaired (caller
+// writes the element back), -1 = fatal.
+//   sed    reference CSR/CPUContext.cpp:230-235   COO/CPUContext.cpp:212-217
+//   sec7   CSR :268-279                          COO :250-258
+//   sec8   CSR :313-335                          COO :293-312
+//   secded CSR :369-400                          COO :346-373
+template <int FMT> struct EccWords { uint32_t w[EccLayout<FMT>::NW]; int rc; };
+
+template <int FMT, int MODE>
+__device__ __noinline__ EccWords<FMT> ecc_cold(EccWords<FMT> e, uint32_t gidx, EventRing ev) {
+  constexpr int EW = EccLayout<FMT>::EW, NBITS = EccLayout<FMT>::NBITS;
+  uint32_t *w = e.w;
+  if (MODE == MODE_SED) {
+    push_event(ev, ABFT_EV_SED_DETECTED, gidx, 0, FMT);
+    e.rc = -1;
+    return e;
+  }
+  const uint32_t h = ecc_hamming<FMT>(w);
+  const uint32_t par = MODE == MODE_SEC7 ? 1u : ecc_parity<FMT>(w);
+  if (par) {
+    if (h) {
+      const uint32_t bit = ecc_position_to_bit<FMT>(h);
+      // static word selects keep the element in registers (no scratch array)
+#pragma unroll
+      for (int k = 0; k < EccLayout<FMT>::NW; k++)
+        if ((bit >> 5) == (uint32_t)k) w[k] ^= 1u << (bit & 31u);
+      (void)NBITS;  // bit >= NBITS (a mis-decoded multi-bit error) selects no word
+      push_event(ev, ABFT_EV_CORRECTED_BIT, gidx, bit, FMT);
+    } else {
+      w[EW] ^= 1u << 24;
+      push_event(ev, ABFT_EV_CORRECTED_PARITY, gidx, 0, FMT);
+    }
+    e.rc = 1;
+    return e;
+  }
+  push_event(ev, ABFT_EV_DOUBLE_BIT, gidx, 0, FMT);  // parity even, syndrome set
+  e.rc = -1;
+  return e;
+}
+
+// Hot-path test: non-zero iff the element needs the cold path.
+template <int FMT, int MODE>
+__device__ __forceinline__ uint32_t ecc_suspect(const uint32_t *w) {
+  if (MODE == MODE_SED || MODE == MODE_SEC8) return ecc_parity<FMT>(w);  // sec8 is lazy
+  if (MODE == MODE_SEC7) return ecc_any_check<FMT>(w);
+  if (MODE == MODE_SECDED) return ecc_any_check<FMT>(w) | ecc_parity<FMT>(w);
+  return 0;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// fixed-shape block reduction (256 threads = 4 waves); result valid in thread 0
+__device__ __forceinline__ double block_sum(double v, double *s_w) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+
+// --------------------------------------------------------------- ECC encode --
+
+// create_matrix's per-element encode (reference CSR/CPUContext.cpp:25-35)
+__global__ __launch_bounds__(ABFT_BLOCK) void encode_csr_kernel(int mode, uint32_t *cols,
+                                                                double *vals, uint32_t nnz) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
+    const double v = vals[i];
+    uint32_t w[3] = {(uint32_t)__double2loint(v), (uint32_t)__double2hiint(v), cols[i]};
+    ecc_encode<FMT_CSR>(mode, w);
+    cols[i] = w[2];
+  }
+}
+
+// reference COO/CPUContext.cpp:22-33
+__global__ __launch_bounds__(ABFT_BLOCK) void encode_coo_kernel(int mode, uint4 *elems, uint32_t nnz) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += gridDim.x * blockDim.x) {
+    uint4 e = elems[i];
+    uint32_t w[4] = {e.x, e.y, e.z, e.w};
+    ecc_encode<FMT_COO>(mode, w);
+    e.x = w[0];
+    elems[i] = e;
+  }
+}
+
+hipError_t launch_encode_csr(int mode, uint32_t *cols, double *vals, uint32_t nnz, hipStream_t s) {
+  if (!nnz || mode < MODE_SED) return hipSuccess;
+  uint32_t grid = (nnz + ABFT_BLOCK - 1) / ABFT_BLOCK;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(encode_csr_kernel, dim3(grid), dim3(ABFT_BLOCK), 0, s, mode, cols, vals, nnz);
+  return hipGetLastError();
+}
+hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s) {
+  if (!nnz || mode < MODE_SED) return hipSuccess;
+  uint32_t grid = (nnz + ABFT_BLOCK - 1) / ABFT_BLOCK;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(encode_coo_kernel, dim3(grid), dim3(ABFT_BLOCK), 0, s, mode, elems, nnz);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------- CSR SpMV --
+
+// One element of the load phase: ECC check (+ repair and write-back), column
+// mask, gather, multiply.  Returns the product.
+template <int MODE>
+__device__ __forceinline__ double csr_element(const CsrDev &A, const double *__restrict__ x,
+                                              const EventRing &ev, uint32_t i, uint32_t lo,
+                                              uint32_t hi, uint32_t c, uint32_t &col_out) {
+  uint32_t w[3] = {lo, hi, c};
+  if (MODE >= MODE_SED) {
+    if (__builtin_expect(ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
+      EccWords<FMT_CSR> e;
+      e.w[0] = w[0]; e.w[1] = w[1]; e.w[2] = w[2]; e.rc = 0;
+      e = ecc_cold<FMT_CSR, MODE>(e, A.index_base + i, ev);
+      w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2];
+      if (e.rc > 0) {  // reference CSR/CPUContext.cpp:275-276, 333-334, 389-390
+        A.vals[i] = as_double(w[0], w[1]);
+        A.cols[i] = w[2];
+      } else {
+        col_out = 0xFFFFFFFFu;
+        return 0.0;
+      }
+    }
+    w[2] &= ABFT_COLMASK;  // reference CSR/CPUContext.cpp:238, 282, 338, 404
+  }
+  col_out = w[2];
+  return as_double(w[0], w[1]) * gather_x(x, w[2], A.n_in);
+}
+
+// Load phase of one tile: elements [lo, hi) of the matrix, staged at LDS slot
+// (i - base); base is even so every thread's pair load is 16-byte aligned.
+// Each wave instruction streams 1 KiB of vals and 512 B of cols, contiguous.
+template <int MODE, int EPT>
+__device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restrict__ x,
+                                          const EventRing &ev, uint32_t base, uint32_t lo,
+                                          uint32_t hi, double *s_prod, uint32_t *s_col) {
+  constexpr int STEPS = EPT / 2;
+  f64x2 v[STEPS];
+  u32x2 c[STEPS];
+#pragma unroll
+  for (int s = 0; s < STEPS; s++) {
+    const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
+    if (i < hi) {  // the arrays are over-allocated by 2: i+1 == hi is still in bounds
+      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(A.vals + i));
+      c[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(A.cols + i));
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < STEPS; s++) {
+    const uint32_t k = 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
+    const uint32_t i = base + k;
+    if (i < hi) {
+      double p0 = 0.0, p1 = 0.0;
+      uint32_t c0 = 0, c1 = 0;
+      if (i >= lo)
+        p0 = csr_element<MODE>(A, x, ev, i, (uint32_t)__double2loint(v[s].x),
+                               (uint32_t)__double2hiint(v[s].x), c[s].x, c0);
+      if (i + 1u < hi)
+        p1 = csr_element<MODE>(A, x, ev, i + 1u, (uint32_t)__double2loint(v[s].y),
+                               (uint32_t)__double2hiint(v[s].y), c[s].y, c1);
+      *reinterpret_cast<double2 *>(s_prod + k) = make_double2(p0, p1);
+      if (MODE == MODE_CONSTRAINTS) *reinterpret_cast<uint2 *>(s_col + k) = make_uint2(c0, c1);
+    }
+  }
+}
+
+// Sum one row from the staged products, in ascending element order.  In
+// constraints mode also runs the reference's structural checks in that order
+// (CSR/CPUContext.cpp:186-200).  Returns false if a fatal event was queued.
+template <int MODE>
+__device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev, uint32_t base,
+                                            uint32_t rs, uint32_t re, uint32_t row_end,
+                                            const double *s_prod, const uint32_t *s_col,
+                                            double &acc) {
+  for (uint32_t i = rs; i < re; i++) {
+    const uint32_t k = i - base;
+    if (MODE == MODE_CONSTRAINTS) {
+      const uint32_t col = s_col[k];
+      if (col >= A.n_in) {
+        push_event(ev, ABFT_EV_COL_SIZE, A.index_base + i, 0, FMT_CSR);
+        return false;
+      }
+      if (i + 1u < row_end) {
+        // the next column is in the tile unless this is the last staged element
+        const uint32_t nxt = (i + 1u < re) ? s_col[k + 1u] : A.cols[i + 1u];
+        if (nxt <= col) {
+          push_event(ev, ABFT_EV_COL_ORDER, A.index_base + i, 0, FMT_CSR);
+          return false;
+        }
+      }
+    }
+    acc += s_prod[k];
+  }
+  return true;
+}
+
+// CSR SpMV, all modes.  A workgroup owns a block of whole rows whose non-zeros
+// fit one LDS tile (row blocks are cut at create time): phase 1 streams the
+// block's cols/vals fully coalesced, checks ECC, gathers x and parks
+// value*x in LDS; phase 2 gives each row to one thread, which adds its
+// products in order.  A row longer than a tile is walked tile by tile with the
+// running sum carried by thread 0 (same order, so still bit-exact).
+//   reference: CSR/CPUContext.cpp:115-133 (none), :162-207 (constraints),
+//              :214-245 (sed), :252-289 (sec7), :297-345 (sec8), :353-411 (secded)
+template <int MODE, int EPT>
+__global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const double *__restrict__ x,
+                                                              double *__restrict__ y, EventRing ev) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[MODE == MODE_CONSTRAINTS ? TILE : 2];
+  const uint32_t t = xcd_tile(blockIdx.x, A.nblk);
+  const uint32_t row0 = A.blk_row[t], row1 = A.blk_row[t + 1];
+  const uint32_t e0 = A.rowptr[row0], e1 = A.rowptr[row1];
+  const uint32_t base = e0 & ~1u;
+
+  if (e1 >= e0 && e1 - base <= TILE) {
+    // row pointers for phase 2, requested before the tile so their latency overlaps
+    const uint32_t r = row0 + threadIdx.x;
+    uint32_t rs = 0, re = 0;
+    if (r < row1) { rs = A.rowptr[r]; re = A.rowptr[r + 1]; }
+    csr_stage<MODE, EPT>(A, x, ev, base, e0, e1, s_prod, s_col);
+    __syncthreads();
+    for (uint32_t row = r; row < row1; row += ABFT_BLOCK) {
+      if (row != r) { rs = A.rowptr[row]; re = A.rowptr[row + 1]; }
+      if (MODE == MODE_CONSTRAINTS) {  // reference CSR/CPUContext.cpp:173-182
+        if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
+        if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
+      }
+      if (rs < e0 || re > e1 || re < rs) continue;  // inconsistent row pointers: never touch LDS out of range
+      double acc = 0.0;
+      if (csr_row_sum<MODE>(A, ev, base, rs, re, re, s_prod, s_col, acc)) y[row] = acc;
+    }
+    return;
+  }
+
+  // long row (or inconsistent pointers): rows of this block one at a time, tile by tile
+  for (uint32_t row = row0; row < row1; row++) {
+    const uint32_t rs = A.rowptr[row], re = A.rowptr[row + 1];
+    if (MODE == MODE_CONSTRAINTS) {
+      if (re > A.nnz) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
+      if (re < rs) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
+    }
+    if (re > A.nnz || re < rs) continue;
+    double acc = 0.0;
+    bool ok = true;
+    for (uint32_t lo = rs; lo < re;) {
+      const uint32_t b = lo & ~1u;
+      const uint32_t hi = min(re, b + TILE);
+      __syncthreads();
+      csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+      __syncthreads();
+      if (threadIdx.x == 0 && ok) ok = csr_row_sum<MODE>(A, ev, b, lo, hi, re, s_prod, s_col, acc);
+      lo = hi;
+    }
+    if (threadIdx.x == 0 && ok) y[row] = acc;
+  }
+}
+
+template <int MODE>
+static hipError_t launch_spmv_csr_mode(const CsrDev &A, const double *x, double *y, EventRing ev,
+                                       hipStream_t s) {
+  hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A, x,
+                     y, ev);
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,
+                           hipStream_t s) {
+  if (A.nblk == 0) return hipSuccess;
+  switch (mode) {
+    case MODE_NONE: return launch_spmv_csr_mode<MODE_NONE>(A, x, y, ev, s);
+    case MODE_CONSTRAINTS: return launch_spmv_csr_mode<MODE_CONSTRAINTS>(A, x, y, ev, s);
+    case MODE_SED: return launch_spmv_csr_mode<MODE_SED>(A, x, y, ev, s);
+    case MODE_SEC7: return launch_spmv_csr_mode<MODE_SEC7>(A, x, y, ev, s);
+    case MODE_SEC8: return launch_spmv_csr_mode<MODE_SEC8>(A, x, y, ev, s);
+    case MODE_SECDED: return launch_spmv_csr_mode<MODE_SECDED>(A, x, y, ev, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ----------------------------------------------------------------- COO SpMV --
+
+// Load phase for COO: one 16-byte element per lane per step (1 KiB per wave
+// instruction), ECC over the 4 words, gather x[row], park value*x in LDS.
+// Constraints mode (reference COO/CPUContext.cpp:155-188) compares with the
+// caller-order successor, reached through the two permutation arrays.
+template <int MODE, int EPT>
+__device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restrict__ x,
+                                          const EventRing &ev, uint32_t lo, uint32_t hi,
+                                          double *s_prod) {
+  u32x4 e[EPT];
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
+    if (j < hi) e[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(A.elems + j));
+  }
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const uint32_t k = threadIdx.x + (uint32_t)s * ABFT_BLOCK;
+    const uint32_t j = lo + k;
+    if (j >= hi) continue;
+    uint32_t w[4] = {e[s].x, e[s].y, e[s].z, e[s].w};
+    double prod = 0.0;
+    bool dead = false;
+    if (MODE == MODE_CONSTRAINTS) {
+      const uint32_t i = A.orig_index[j];
+      const uint32_t gi = A.index_base + i;
+      if (w[1] >= A.n_in) { push_event(ev, ABFT_EV_ROW_SIZE, gi, 0, FMT_COO); dead = true; }
+      else if (w[0] >= A.n_out) { push_event(ev, ABFT_EV_COL_SIZE, gi, 0, FMT_COO); dead = true; }
+      else if (i + 1u < A.nnz) {
+        const uint4 nx = A.elems[A.pos_of_orig[i + 1u]];
+        if (w[1] > nx.y) { push_event(ev, ABFT_EV_ROW_ORDER, gi, 0, FMT_COO); dead = true; }
+        else if (w[1] == nx.y && w[0] >= nx.x) { push_event(ev, ABFT_EV_COL_ORDER, gi, 0, FMT_COO); dead = true; }
+      }
+    } else if (MODE >= MODE_SED) {
+      if (__builtin_expect(ecc_suspect<FMT_COO, MODE>(w) != 0, 0)) {
+        EccWords<FMT_COO> ce;
+        ce.w[0] = w[0]; ce.w[1] = w[1]; ce.w[2] = w[2]; ce.w[3] = w[3]; ce.rc = 0;
+        ce = ecc_cold<FMT_COO, MODE>(ce, A.index_base + A.orig_index[j], ev);
+        w[0] = ce.w[0]; w[1] = ce.w[1]; w[2] = ce.w[2]; w[3] = ce.w[3];
+        if (ce.rc > 0) A.elems[j] = make_uint4(w[0], w[1], w[2], w[3]);  // COO/CPUContext.cpp:255, 310, 364
+        else dead = true;
+      }
+    }
+    if (!dead) prod = as_double(w[2], w[3]) * gather_x(x, w[1], A.n_in);
+    s_prod[k] = prod;
+  }
+}
+
+// COO SpMV, all modes: result[col] += value * vec[row] (reference
+// COO/CPUContext.cpp:104-121).  Elements are stored grouped by col in caller
+// order, so an output's contributions are added in exactly the order the
+// reference's serial loop adds them; the workgroup/tile structure is the CSR
+// one with (group, grp_ptr) in place of (row, rowptr).
+template <int MODE, int EPT>
+__global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const double *__restrict__ x,
+                                                              double *__restrict__ y, EventRing ev) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  const uint32_t t = xcd_tile(blockIdx.x, A.nblk);
+  const uint32_t g0 = A.blk_grp[t], g1 = A.blk_grp[t + 1];
+  const uint32_t e0 = A.grp_ptr[g0], e1 = A.grp_ptr[g1];
+
+  if (e1 - e0 <= TILE) {
+    const uint32_t g = g0 + threadIdx.x;
+    uint32_t gs = 0, ge = 0;
+    if (g < g1) { gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1]; }
+    coo_stage<MODE, EPT>(A, x, ev, e0, e1, s_prod);
+    __syncthreads();
+    for (uint32_t grp = g; grp < g1; grp += ABFT_BLOCK) {
+      if (grp != g) { gs = A.grp_ptr[grp]; ge = A.grp_ptr[grp + 1]; }
+      double acc = 0.0;  // reference zero-fills result first (COO/CPUContext.cpp:108-109)
+      for (uint32_t j = gs; j < ge; j++) acc += s_prod[j - e0];
+      y[grp] = acc;
+    }
+    return;
+  }
+
+  for (uint32_t grp = g0; grp < g1; grp++) {  // a group longer than a tile
+    const uint32_t gs = A.grp_ptr[grp], ge = A.grp_ptr[grp + 1];
+    double acc = 0.0;
+    for (uint32_t lo = gs; lo < ge;) {
+      const uint32_t hi = min(ge, lo + TILE);
+      __syncthreads();
+      coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod);
+      __syncthreads();
+      if (threadIdx.x == 0)
+        for (uint32_t j = lo; j < hi; j++) acc += s_prod[j - lo];
+      lo = hi;
+    }
+    if (threadIdx.x == 0) y[grp] = acc;
+  }
+}
+
+template <int MODE>
+static hipError_t launch_spmv_coo_mode(const CooDev &A, const double *x, double *y, EventRing ev,
+                                       hipStream_t s) {
+  hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A, x,
+                     y, ev);
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
+                           hipStream_t s) {
+  if (A.nblk == 0) return hipSuccess;
+  switch (mode) {
+    case MODE_NONE: return launch_spmv_coo_mode<MODE_NONE>(A, x, y, ev, s);
+    case MODE_CONSTRAINTS: return launch_spmv_coo_mode<MODE_CONSTRAINTS>(A, x, y, ev, s);
+    case MODE_SED: return launch_spmv_coo_mode<MODE_SED>(A, x, y, ev, s);
+    case MODE_SEC7: return launch_spmv_coo_mode<MODE_SEC7>(A, x, y, ev, s);
+    case MODE_SEC8: return launch_spmv_coo_mode<MODE_SEC8>(A, x, y, ev, s);
+    case MODE_SECDED: return launch_spmv_coo_mode<MODE_SECDED>(A, x, y, ev, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ------------------------------------------------------------ fault injection --
+
+// The XOR half of inject_bitflip (reference CSR/CPUContext.cpp:146-158); the
+// rand() draws stay on the host.
+__global__ void inject_csr_kernel(double *vals, uint32_t *cols, uint32_t index, const int *bits, int nbits) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint32_t *vw = reinterpret_cast<uint32_t *>(vals + index);
+  for (int k = 0; k < nbits; k++) {
+    const int bit = bits[k];
+    if (bit < 64) vw[bit >> 5] ^= 1u << (bit & 31);
+    else cols[index] ^= 1u << (bit & 31);
+  }
+}
+
+// reference COO/CPUContext.cpp:134-139
+__global__ void inject_coo_kernel(uint4 *elems, const uint32_t *pos_of_orig, uint32_t index,
+                                  const int *bits, int nbits) {
+  if (blockIdx.x || threadIdx.x) return;
+  uint32_t *w = reinterpret_cast<uint32_t *>(elems + pos_of_orig[index]);
+  for (int k = 0; k < nbits; k++) w[bits[k] >> 5] ^= 1u << (bits[k] & 31);
+}
+
+hipError_t launch_inject_csr(double *vals, uint32_t *cols, uint32_t index, const int *bits_dev,
+                             int nbits, hipStream_t s) {
+  hipLaunchKernelGGL(inject_csr_kernel, dim3(1), dim3(64), 0, s, vals, cols, index, bits_dev, nbits);
+  return hipGetLastError();
+}
+hipError_t launch_inject_coo(uint4 *elems, const uint32_t *pos_of_orig, uint32_t index,
+                             const int *bits_dev, int nbits, hipStream_t s) {
+  hipLaunchKernelGGL(inject_coo_kernel, dim3(1), dim3(64), 0, s, elems, pos_of_orig, index, bits_dev, nbits);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------- vector kernels --
+
+int reduce_blocks(int n) {
+  long per_block = (long)ABFT_BLOCK * 8;  // >= 8 elements per thread before adding blocks
+  long nb = (n + per_block - 1) / per_block;
+  if (nb < 1) nb = 1;
+  if (nb > ABFT_MAX_PARTIALS) nb = ABFT_MAX_PARTIALS;
+  return (int)nb;
+}
+
+// dot, stage 1 (reference CSR/CPUContext.cpp:82-90).  VEC=2: 16-byte loads.
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void dot_kernel(const double *__restrict__ a,
+                                                         const double *__restrict__ b, int n,
+                                                         double *__restrict__ partials) {
+  __shared__ double s_w[4];
+  double acc = 0.0;
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n) {
+      const double2 av = *reinterpret_cast<const double2 *>(a + i);
+      const double2 bv = *reinterpret_cast<const double2 *>(b + i);
+      acc += av.x * bv.x;
+      acc += av.y * bv.y;
+    } else {
+      acc += a[i] * b[i];
+    }
+  }
+  acc = block_sum(acc, s_w);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// calc_xr, stage 1 (reference CSR/CPUContext.cpp:92-105): x += alpha p;
+// r -= alpha w; partial of r.r with the updated r.
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void calc_xr_kernel(double *__restrict__ x, double *__restrict__ r,
+                                                             const double *__restrict__ p,
+                                                             const double *__restrict__ w, double alpha,
+                                                             int n, double *__restrict__ partials) {
+  __shared__ double s_w[4];
+  double acc = 0.0;
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n) {
+      double2 xv = *reinterpret_cast<double2 *>(x + i);
+      double2 rv = *reinterpret_cast<double2 *>(r + i);
+      const double2 pv = *reinterpret_cast<const double2 *>(p + i);
+      const double2 wv = *reinterpret_cast<const double2 *>(w + i);
+      xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+      rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
+      *reinterpret_cast<double2 *>(x + i) = xv;
+      *reinterpret_cast<double2 *>(r + i) = rv;
+      acc += rv.x * rv.x;
+      acc += rv.y * rv.y;
+    } else {
+      const double xs = x[i] + alpha * p[i];
+      const double rs = r[i] - alpha * w[i];
+      x[i] = xs;
+      r[i] = rs;
+      acc += rs * rs;
+    }
+  }
+  acc = block_sum(acc, s_w);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// stage 2: one block adds the partials in a fixed order and publishes the
+// scalar (and the event count, so a queued ECC event reaches the host with the
+// same synchronisation that returns the dot product).
+__global__ __launch_bounds__(ABFT_BLOCK) void finalize_kernel(const double *__restrict__ partials, int nparts,
+                                                              double *dev_out, double *host_out,
+                                                              const uint32_t *ev_count,
+                                                              uint32_t *host_evcount) {
+  __shared__ double s_w[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += ABFT_BLOCK) acc += partials[i];
+  acc = block_sum(acc, s_w);
+  if (threadIdx.x == 0) {
+    if (dev_out) {  // shard-local form: {partial sum, queued events} for one all-reduce
+      dev_out[0] = acc;
+      dev_out[1] = ev_count ? (double)*ev_count : 0.0;
+    }
+    if (host_out) *host_out = acc;
+    if (host_evcount && ev_count) *host_evcount = *ev_count;
+  }
+}
+
+// calc_p (reference CSR/CPUContext.cpp:107-113): p = r + beta p
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void calc_p_kernel(double *__restrict__ p, const double *__restrict__ r,
+                                                            double beta, int n) {
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n) {
+      double2 pv = *reinterpret_cast<double2 *>(p + i);
+      const double2 rv = *reinterpret_cast<const double2 *>(r + i);
+      pv.x = rv.x + beta * pv.x;
+      pv.y = rv.y + beta * pv.y;
+      *reinterpret_cast<double2 *>(p + i) = pv;
+    } else {
+      p[i] = r[i] + beta * p[i];
+    }
+  }
+}
+
+static inline bool aligned16(const void *a, const void *b = nullptr, const void *c = nullptr,
+                             const void *d = nullptr) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
+}
+
+hipError_t launch_dot(const double *a, const double *b, int n, double *partials, hipStream_t s) {
+  const int nb = reduce_blocks(n);
+  if (aligned16(a, b))
+    hipLaunchKernelGGL(dot_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, a, b, n, partials);
+  else
+    hipLaunchKernelGGL(dot_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, a, b, n, partials);
+  return hipGetLastError();
+}
+
+hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w, double alpha, int n,
+                          double *partials, hipStream_t s) {
+  const int nb = reduce_blocks(n);
+  if (aligned16(x, r, p, w))
+    hipLaunchKernelGGL(calc_xr_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, partials);
+  else
+    hipLaunchKernelGGL(calc_xr_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, partials);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(const double *partials, int nparts, double *dev_out, double *host_out,
+                           const uint32_t *ev_count, uint32_t *host_evcount, hipStream_t s) {
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(ABFT_BLOCK), 0, s, partials, nparts, dev_out, host_out,
+                     ev_count, host_evcount);
+  return hipGetLastError();
+}
+
+hipError_t launch_calc_p(double *p, const double *r, double beta, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int nb = reduce_blocks(n);
+  if (aligned16(p, r))
+    hipLaunchKernelGGL(calc_p_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, beta, n);
+  else
+    hipLaunchKernelGGL(calc_p_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, beta, n);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------ bandwidth probe --
+
+__global__ __launch_bounds__(ABFT_BLOCK) void stream_copy_kernel(double2 *__restrict__ dst,
+                                                                 const double2 *__restrict__ src, size_t n2) {
+  const size_t stride = (size_t)gridDim.x * ABFT_BLOCK;
+  for (size_t i = (size_t)blockIdx.x * ABFT_BLOCK + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(ABFT_BLOCK) void stream_read_kernel(const double2 *__restrict__ src, size_t n2,
+                                                                 double *sink) {
+  const size_t stride = (size_t)gridDim.x * ABFT_BLOCK;
+  double acc = 0.0;
+  for (size_t i = (size_t)blockIdx.x * ABFT_BLOCK + threadIdx.x; i < n2; i += stride) {
+    const double2 v = src[i];
+    acc += v.x + v.y;
+  }
+  if (acc == 1.2345e-300) *sink = acc;  // keeps the loads alive, never true in practice
+}
+
+hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(ABFT_BLOCK), 0, s, (double2 *)dst,
+                     (const double2 *)src, n / 2);
+  return hipGetLastError();
+}
+hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s) {
+  hipLaunchKernelGGL(stream_read_kernel, dim3(256 * 8), dim3(ABFT_BLOCK), 0, s, (const double2 *)src, n / 2,
+                     sink);
+  return hipGetLastError();
+}

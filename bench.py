@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/s and SpMV effective HBM GB/s of the hip target.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one CG iteration driven through the C ABI exactly as the reference
+driver drives a backend (cg.cpp:97-112): spmv, dot, calc_xr, calc_p, with the
+two scalars returned to the host.  The workload is BASELINE.json configs[1]:
+`cg-csr -t hip -m none` on the synthetic 5-point Laplacian 3162 x 3162
+(N = 9,998,244, nnz = 49,978,572), b = uniform(0,1), x0 = 0, fixed iteration
+count (-c 0).  For N > 1 the same matrix is row-partitioned over the ranks
+(strong scaling): each rank builds its own shard, the search-vector exchange and
+the two all-reduces go through torch.distributed (RCCL).
+
+Rank 0 prints ONE JSON line; see the keys at the bottom.  The matrix, vectors and
+the CPU baseline are built outside the timed region; inputs are resident in HBM
+when the clock starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak reported beside it
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spec", default="laplace5:3162,3162", help="synthetic matrix (generators.cpp)")
+    ap.add_argument("--mode", default="none")
+    ap.add_argument("--fmt", default="csr", choices=["csr", "coo"])
+    ap.add_argument("--cpu-iters", type=int, default=40, help="CG iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket SpMV launches with HIP events")
+    ap.add_argument("--probe", action="store_true", help="also measure the streaming-copy bandwidth of the device")
+    return ap.parse_args()
+
+
+def spmv_bytes(fmt, n, nnz):
+    """Algorithmic bytes of one SpMV (SURVEY 8d / BASELINE.md section 5)."""
+    return 12 * nnz + 20 * n + 4 if fmt == "csr" else 16 * nnz + 16 * n
+
+
+def traffic_from_profile(workload):
+    """HBM bytes per SpMV launch from the committed rocprofv3 PMC summary, if any."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    try:
+        d = json.load(open(path))
+        return d.get(workload, {}).get("spmv_hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def single(args):
+    import numpy as np
+    import torch
+
+    import abft_sparse_cg_amd as amd
+    from abft_sparse_cg_amd import capi, generators
+
+    cols, rows, vals, n = generators.generate(args.spec)
+    nnz = len(vals)
+    ctx = amd.HIPContext(args.mode, args.fmt, device=0)
+    A = ctx.create_matrix(cols, rows, vals, n, nnz)
+    b, x, r, p, w = (ctx.create_vector(n) for _ in range(5))
+    ctx.upload(b, np.random.default_rng(1).random(n))
+    ctx.upload(x, np.zeros(n))
+    ctx.copy_vector(r, b)
+    ctx.copy_vector(p, r)
+    state = {"rr": ctx.dot(r, r)}
+
+    def step():
+        ctx.spmv(A, p, w)
+        pw = ctx.dot(p, w)
+        alpha = state["rr"] / pw
+        rr_new = ctx.calc_xr(x, r, p, w, alpha)
+        ctx.calc_p(p, r, rr_new / state["rr"])
+        state["rr"] = rr_new
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        ctx.profile(True)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+
+    roof = None
+    kernels = {}
+    if not args.no_profile:
+        names = {capi.K_SPMV: "spmv", capi.K_DOT: "dot", capi.K_CALC_XR: "calc_xr", capi.K_CALC_P: "calc_p"}
+        byts = {"spmv": spmv_bytes(args.fmt, n, nnz), "dot": 16 * n, "calc_xr": 48 * n, "calc_p": 24 * n}
+        for k, name in names.items():
+            ms, cnt = ctx.profile_read(k)
+            if cnt:
+                us = ms * 1e3 / cnt
+                kernels[name] = {"avg_us": round(us, 2), "launches": cnt, "GBps": round(byts[name] / us / 1e3, 1)}
+        if "spmv" in kernels:
+            ach = kernels["spmv"]["GBps"]
+            workload = "%s/%s/%s" % (args.spec, args.fmt, args.mode)
+            roof = {"bound": "hbm", "kernel": "spmv_%s_kernel<%s>" % (args.fmt, args.mode), "achieved": ach,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "traffic": traffic_from_profile(workload), "avg_launch_us": kernels["spmv"]["avg_us"],
+                    "algorithmic_bytes_per_launch": byts["spmv"]}
+    probe = None
+    if args.probe:
+        c, rd = ctx.stream_probe(1 << 30, 10)
+        probe = {"copy_GBps": round(c, 1), "read_GBps": round(rd, 1)}
+        if roof:
+            roof["measured_copy_peak"] = probe["copy_GBps"]
+            roof["frac_of_measured_copy"] = round(roof["achieved"] / c, 4)
+    rr_final = state["rr"]
+    ctx.close()
+
+    cpu = None
+    if args.cpu_iters > 0 and args.fmt == "csr":
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import baseline  # the CPU checker, timed as a baseline only
+        res = baseline.time_cg(cols, rows, vals, n, args.mode, args.cpu_iters)
+        cpu = {"value": round(res["it_per_s"], 3), "unit": "CG iterations/s", "cores": res["cores"],
+               "kind": res["kind"],
+               "sample": "%d CG iterations of the same matrix (%s, -m %s), OpenMP spmv + serial vector ops as the "
+                         "reference, %.1f s" % (res["iters"], args.spec, args.mode, res["seconds"])}
+    return dt, n, nnz, roof, kernels, cpu, probe, rr_final
+
+
+def sharded(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from abft_sparse_cg_amd import capi, generators
+    from abft_sparse_cg_amd.distributed import HipEngine, ShardedCG
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
+    if args.fmt != "csr":
+        raise SystemExit("the row-partitioned solver shards CSR; COO runs on one GPU")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    n = generators.dim(args.spec)
+    bounds = generators.partition(args.spec, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    cols, rows, vals, _ = generators.generate(args.spec, r0, r1)
+    counts = [None] * world
+    dist.all_gather_object(counts, len(vals))
+    nnz = sum(counts)
+    eng = HipEngine(args.mode, "csr", device=local)
+    cg = ShardedCG(eng, cols, rows, vals, bounds, sum(counts[:rank]), args.mode)
+    del cols, rows, vals
+    cg.set_rhs(np.random.default_rng(1).random(n)[r0:r1])
+    cg.start()
+    for _ in range(args.warmup):
+        cg.step()
+    if not args.no_profile:
+        eng.ctx.profile(True)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cg.step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    roof, kernels = None, {}
+    if not args.no_profile:
+        ms, cnt = eng.ctx.profile_read(capi.K_SPMV)
+        if cnt:
+            us = ms * 1e3 / cnt
+            byts = spmv_bytes("csr", cg.n_loc, counts[rank])
+            ach = byts / us / 1e3
+            kernels["spmv"] = {"avg_us": round(us, 2), "launches": cnt, "GBps": round(ach, 1), "rank": rank}
+            roof = {"bound": "hbm", "kernel": "spmv_csr_kernel<%s> (rank 0 shard)" % args.mode,
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_us": round(us, 2),
+                    "algorithmic_bytes_per_launch": byts}
+    rr_final = cg.rr
+    exchange = "windows" if cg.use_windows else "all_gather"
+    eng.close()
+    dist.destroy_process_group()
+    return rank, dt, n, nnz, roof, kernels, rr_final, exchange
+
+
+def main():
+    args = parse()
+    base = {"metric": "CG iterations/sec + SpMV effective HBM GB/s (% of roofline), 1/2/4/8 MI355X",
+            "unit": "CG iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic"}
+    if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        dt, n, nnz, roof, kernels, cpu, probe, rr = single(args)
+        out = dict(base)
+        out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                    "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec)
+                               if args.fmt == "csr" else "cg-coo -t hip -m %s, synthetic %s" % (args.mode, args.spec),
+                               "N": n, "nnz": nnz, "format": args.fmt, "mode": args.mode, "parallelism": "1 GPU",
+                               "rr_after_last_step": rr},
+                    "roofline": roof, "cpu_baseline": cpu, "kernels": kernels})
+        if probe:
+            out["stream_probe"] = probe
+        print(json.dumps(out))
+        return
+    rank, dt, n, nnz, roof, kernels, rr, exchange = sharded(args)
+    if rank == 0:
+        out = dict(base)
+        out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                    "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec), "N": n,
+                               "nnz": nnz, "format": "csr", "mode": args.mode,
+                               "parallelism": "row-block x%d, %s exchange + 2 all-reduce / iteration"
+                                              % (args.gpus, exchange),
+                               "rr_after_last_step": rr},
+                    "roofline": roof, "cpu_baseline": None, "kernels": kernels})
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

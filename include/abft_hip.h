@@ -105,12 +105,13 @@ int abft_hip_matrix_create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *colu
 int abft_hip_matrix_create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns,
                                const uint32_t *rows, const double *values, int N, int nnz,
                                abft_hip_matrix **mat);
-/* Row-block shard of a larger matrix (multi-GPU): `nrows` local
- * rows (row indices local, 0-based), columns index a vector of length `ncols`,
- * event indices are reported as index_base + local i. */
+/* Row-block shard of a larger matrix (multi-GPU): the result vector
+ * has `n_out` entries (CSR: local rows, COO: local cols, 0-based), the input
+ * vector `n_in` entries (CSR: columns index it, COO: rows do); event indices
+ * are reported as index_base + local element index. */
 int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int mode,
                                  const uint32_t *columns, const uint32_t *rows,
-                                 const double *values, int nrows, int ncols, int nnz,
+                                 const double *values, int n_out, int n_in, int nnz,
                                  uint32_t index_base, abft_hip_matrix **mat);
 /* reference CSR/CPUContext.cpp:46-52 */
 int abft_hip_matrix_destroy(abft_hip_matrix *mat);
@@ -164,8 +165,10 @@ int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector
                   abft_hip_vector *result);
 
 /* Shard-local forms for the row-partitioned solver: same kernels, but the
- * scalar stays on the device (`dev_result` is a device pointer to one double)
- * so a collective can sum it across ranks before the host reads it. */
+ * result stays on the device so a collective can sum it across ranks before
+ * the host reads it.  `dev_result` is a device pointer to TWO doubles:
+ * [0] = the shard's partial sum, [1] = this context's queued-event count
+ * (so one all-reduce also tells every rank whether any rank has events). */
 int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b,
                      double *dev_result);
 int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,

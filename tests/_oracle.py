@@ -344,6 +344,38 @@ class Ref:
         return it, hist[:it].copy(), x
 
 
+# ---- helpers that run INSIDE a captured child (tests/_capture.run_captured) ----
+
+def ref_flip_spmv(fmt, mode, mat, index, bits, x, passes=2):
+    """flip `bits` of element `index`, then `passes` SpMVs -> ([y...], stored words)"""
+    cols, rows, vals, n = mat
+    r = Ref(fmt, mode, cols, rows, vals, n)
+    r.flip(index, bits)
+    ys = [r.spmv(x) for _ in range(passes)]
+    return ys, r.stored_words()
+
+
+def ref_cg(fmt, mode, mat, b, max_itrs=1000, conv=1e-3):
+    cols, rows, vals, n = mat
+    return Ref(fmt, mode, cols, rows, vals, n).cg(b, max_itrs, conv)
+
+
+def ref_inject_rand(fmt, mat, seed, kind, flips):
+    """srand(seed); inject_bitflip(kind, flips) -> stored words (prints the flip lines)"""
+    cols, rows, vals, n = mat
+    C.CDLL(None).srand(seed)
+    r = Ref(fmt, "none", cols, rows, vals, n)
+    r.L.ref_inject_rand(r.ctx, r.mat, kind, flips)
+    r.L.ref_flush()
+    return r.stored_words()
+
+
+def ref_encode(fmt, mode, mat):
+    cols, rows, vals, n = mat
+    r = Ref(fmt, mode, cols, rows, vals, n)
+    return r.stored_words(), (r.rowptr() if fmt == CSR else None)
+
+
 # --------------------------------------------------------- small test matrices --
 
 def laplace5(nx, ny):

@@ -31,7 +31,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 
 from _capture import run_captured  # noqa: E402
-from _oracle import COO, CSR, FMT_NAME, MODES, Ref, have_ref, laplace5, random_spd, ref_exe, rhs  # noqa: E402
+from _oracle import (COO, CSR, FMT_NAME, MODES, Ref, have_ref, laplace5, random_spd, ref_cg, ref_encode,  # noqa: E402
+                     ref_exe, ref_flip_spmv, rhs)
 
 u32p = C.POINTER(C.c_uint32)
 NW = {CSR: 3, COO: 4}
@@ -99,7 +100,8 @@ def mats():
 
 def gen_kernels():
     arrs = {}
-    for name, (cols, rows, vals, n) in mats().items():
+    for name, mat in mats().items():
+        cols, rows, vals, n = mat
         arrs[name + "_cols"], arrs[name + "_rows"], arrs[name + "_vals"] = cols, rows, vals
         arrs[name + "_n"] = np.array([n])
         x = rhs(n, 11) - 0.5
@@ -108,25 +110,17 @@ def gen_kernels():
         for fmt in (CSR, COO):
             for mode in MODES:
                 key = "%s_%s_%s" % (name, FMT_NAME[fmt], mode)
-                r = Ref(fmt, mode, cols, rows, vals, n)
-                arrs[key + "_words"] = r.stored_words()
-                code, text, y = run_captured(r.spmv, x)
+                code, text, (words, _) = run_captured(ref_encode, fmt, mode, mat)
+                assert code == 0
+                arrs[key + "_words"] = words
+                code, text, ((y,), _) = run_captured(ref_flip_spmv, fmt, mode, mat, 0, [], x, 1)
                 assert code == 0 and text == "", (key, code, text)
                 arrs[key + "_y"] = y
-                code, text, (it, hist, xs) = run_captured(r.cg, b)
+                code, text, (it, hist, xs) = run_captured(ref_cg, fmt, mode, mat, b)
                 assert code == 0
                 arrs[key + "_rr"] = hist
                 arrs[key + "_xsol"] = xs
     return arrs
-
-
-def _flip_case(fmt, mode, mat, index, bits, x):
-    cols, rows, vals, n = mat
-    r = Ref(fmt, mode, cols, rows, vals, n)
-    r.flip(index, bits)
-    y1 = r.spmv(x)
-    y2 = r.spmv(x)
-    return y1, y2, r.stored_words()
 
 
 def gen_flips():
@@ -147,14 +141,20 @@ def gen_flips():
                     b = rng.choice(nb, size=2, replace=False)
                     picks.append((int(rng.integers(0, len(vals))), [int(b[0]), int(b[1])]))
             for index, bits in picks:
-                code, text, res = run_captured(_flip_case, fmt, mode, mat, index, bits, x)
+                code, text, res = run_captured(ref_flip_spmv, fmt, mode, mat, index, bits, x, 2)
                 if code not in (0, 1):
                     continue  # reference itself faulted (UB on a wild gather index)
                 c = {"matrix": name, "fmt": FMT_NAME[fmt], "mode": mode, "index": index, "bits": bits,
                      "exit": code, "stdout": text}
                 if code == 0:
-                    c["y1"], c["y2"] = hexd(res[0]), hexd(res[1])
-                    c["words_after"] = [[int(v) for v in row] for row in res[2][index:index + 1]]
+                    w = [int(v) for v in res[1][index]]
+                    ecc = mode != "constraints"
+                    gather = (w[2] & 0xFFFFFF if ecc else w[2]) if fmt == CSR else w[1]
+                    scatter = 0 if fmt == CSR else (w[0] & 0xFFFFFF if ecc else w[0])
+                    if gather >= n or scatter >= n:
+                        continue  # the reference indexed outside its vectors (UB): not a vector
+                    c["y1"], c["y2"] = hexd(res[0][0]), hexd(res[0][1])
+                    c["words_after"] = [[int(v) for v in row] for row in res[1][index:index + 1]]
                 cases.append(c)
     return cases
 

@@ -1,0 +1,407 @@
+"""Parity of the HIP path (through the C ABI, libabft_hip.so) against the CPU
+oracle on the same seeded inputs and against the committed golden vectors.
+
+Bars (BASELINE.json north_star):
+  * stored (ECC-encoded) elements, SpMV results, element-wise results of
+    calc_xr / calc_p, ECC / constraint event streams: BIT-EXACT;
+  * the two reductions (dot, calc_xr's r.r) are tree sums on the GPU and serial
+    sums in the reference: relative 1e-13 here (target: residual within 1e-10);
+  * CG: identical iteration count, rr history within 1e-10 relative.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+from _oracle import (COO, CSR, MODES, OracleMatrix, event_lines, laplace5, ora_calc_p, ora_calc_xr, ora_dot,
+                     random_spd, rhs)
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FMTS = [CSR, COO]
+FNAME = {CSR: "csr", COO: "coo"}
+NBITS = {CSR: 96, COO: 128}
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import abft_sparse_cg_amd as a
+    return a
+
+
+class Hip:
+    """One HIPContext + matrix + work vectors, events collected not printed."""
+
+    def __init__(self, amd, fmt, mode, cols, rows, vals, n, n_in=None, index_base=0):
+        self.events, self.fatal = [], False
+        self.ctx = amd.HIPContext(mode, FNAME[fmt], on_event=self._on)
+        self.fmt, self.n, self.n_in = fmt, n, n if n_in is None else n_in
+        self.A = self.ctx.create_matrix(cols, rows, vals, n, len(vals), n_in=n_in, index_base=index_base)
+        self.vx = self.ctx.create_vector(self.n_in)
+        self.vy = self.ctx.create_vector(n)
+
+    def _on(self, ev, fatal):
+        self.events += ev
+        self.fatal |= fatal
+
+    def spmv(self, x):
+        self.ctx.upload(self.vx, x)
+        self.ctx.upload(self.vy, np.full(self.n, np.nan))
+        self.ctx.spmv(self.A, self.vx, self.vy)
+        return self.ctx.download(self.vy)
+
+    def take_events(self):
+        ev, f = self.events, self.fatal
+        self.events, self.fatal = [], False
+        return ev, f
+
+    def close(self):
+        self.ctx.destroy_vector(self.vx)
+        self.ctx.destroy_vector(self.vy)
+        self.ctx.destroy_matrix(self.A)
+        self.ctx.close()
+
+
+def coo_col_moved(o, index, cols):
+    """COO only: the element's stored column (low 24 bits) no longer names its
+    original output row.  The reference then scatters into the corrupted row; the
+    HIP path keeps the element in its original group (deliberate
+    divergence on silently corrupted data), so y is not compared."""
+    return o.fmt == COO and (int(o.stored_words()[index][0]) & 0xFFFFFF) != int(cols[index])
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+def ragged(n, seed, long_rows=()):
+    """Irregular square matrix: empty rows, 1-entry rows, a few rows longer than
+    one LDS tile (1024 nnz) and than several tiles; sorted by (row, col)."""
+    rng = np.random.default_rng(seed)
+    rows, cols = [], []
+    for r in range(n):
+        k = int(rng.choice([0, 0, 1, 2, 3, 7, 20, 60]))
+        if r in long_rows:
+            k = long_rows[r]
+        k = min(k, n)
+        c = np.sort(rng.choice(n, size=k, replace=False))
+        rows.append(np.full(k, r))
+        cols.append(c)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    vals = rng.standard_normal(len(rows)) * 10.0 ** rng.integers(-3, 4, size=len(rows))
+    return cols.astype(np.uint32), rows.astype(np.uint32), vals, n
+
+
+MATS = {
+    "lap9x7": lambda: laplace5(9, 7),
+    "lap40": lambda: laplace5(40, 33),
+    "rnd300": lambda: random_spd(300, 10, seed=5),
+    "ragged": lambda: ragged(700, 1, {5: 1500, 6: 3, 300: 5000, 699: 1025}),
+    "one": lambda: (np.array([0], np.uint32), np.array([0], np.uint32), np.array([2.5]), 1),
+    "empty": lambda: (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0), 5),
+    "tail_empty": lambda: (np.array([0, 1], np.uint32), np.array([0, 0], np.uint32), np.array([1.0, 2.0]), 2000),
+}
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("mat", sorted(MATS))
+def test_spmv_and_encoding_bit_exact(amd, fmt, mode, mat):
+    cols, rows, vals, n = MATS[mat]()
+    x = rhs(n, 11) - 0.5
+    o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+    h = Hip(amd, fmt, mode, cols, rows, vals, n)
+    try:
+        assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+        if fmt == CSR:
+            assert np.array_equal(h.ctx.rowptr(h.A), o.csr_arrays()[1])
+        y = h.spmv(x)
+        want = o.spmv(x)
+        ev, fatal = h.take_events()
+        if mat == "ragged" and mode == "constraints":
+            # unordered duplicates never occur, but equal neighbours are legal input here: same verdict
+            oev, ofatal = o.events()
+            assert (ev, fatal) == (oev, ofatal)
+            if fatal:
+                return
+        else:
+            assert ev == [] and not fatal
+        assert bits_equal(y, want)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("mode", ["sed", "sec7", "sec8", "secded"])
+def test_every_single_bit_flip(amd, fmt, mode):
+    """All 96 / 128 positions of one element: same event line, same repaired
+    element, same y on this pass and the next (write-back persists)."""
+    cols, rows, vals, n = random_spd(64, 6, seed=9)
+    x = rhs(n, 2) + 0.25
+    index = len(vals) // 2
+    h = Hip(amd, fmt, mode, cols, rows, vals, n)
+    clean = h.ctx.stored_words(h.A)[index].copy()
+    try:
+        for bit in range(NBITS[fmt]):
+            o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+            o.inject(index, [bit])
+            h.ctx.inject_at(h.A, index, [bit])
+            assert np.array_equal(h.ctx.stored_words(h.A)[index], o.stored_words()[index])
+            y1 = h.spmv(x)
+            ev, fatal = h.take_events()
+            w1 = o.spmv(x)
+            oev, ofatal = o.events()
+            assert (ev, fatal) == (oev, ofatal), bit
+            assert event_lines(ev, fmt) == event_lines(oev, fmt)
+            if fatal:
+                h.ctx.inject_at(h.A, index, [bit])  # undo: sed cannot repair
+            else:
+                assert bits_equal(y1, w1), bit
+                y2, w2 = h.spmv(x), o.spmv(x)
+                assert h.take_events() == o.events()
+                assert bits_equal(y2, w2), bit
+                assert np.array_equal(h.ctx.stored_words(h.A)[index], o.stored_words()[index]), bit
+                if mode == "sec7" and bit == (88 if fmt == CSR else 24):
+                    h.ctx.inject_at(h.A, index, [bit])  # sec7's blind spot: undo by hand
+            assert np.array_equal(h.ctx.stored_words(h.A)[index], clean), bit
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("mode", ["sec7", "sec8", "secded"])
+def test_double_bit_flips(amd, fmt, mode):
+    cols, rows, vals, n = random_spd(64, 6, seed=10)
+    x = rhs(n, 3) + 0.25
+    rng = np.random.default_rng(1)
+    for _ in range(40):
+        index = int(rng.integers(0, len(vals)))
+        b1, b2 = (int(b) for b in rng.choice(NBITS[fmt], size=2, replace=False))
+        o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+        o.inject(index, [b1, b2])
+        h = Hip(amd, fmt, mode, cols, rows, vals, n)
+        try:
+            h.ctx.inject_at(h.A, index, [b1, b2])
+            y, want = h.spmv(x), o.spmv(x)
+            ev, fatal = h.take_events()
+            assert (ev, fatal) == o.events(), (index, b1, b2)
+            if mode == "secded":
+                assert fatal and event_lines(ev, fmt) == ["[ECC] double-bit error detected\n"]
+            elif not fatal and not coo_col_moved(o, index, cols):
+                assert bits_equal(y, want), (index, b1, b2)
+                assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+        finally:
+            h.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_constraints_mode_detects_like_reference(amd, fmt):
+    cols, rows, vals, n = random_spd(50, 6, seed=4)
+    x = rhs(n, 5)
+    idx_bits = range(64, 96) if fmt == CSR else range(0, 64)
+    fatal_seen = 0
+    for index in (0, 5, len(vals) - 1, len(vals) // 3):
+        for bit in idx_bits:
+            o = OracleMatrix(fmt, "constraints", cols, rows, vals, n)
+            o.inject(index, [bit])
+            h = Hip(amd, fmt, "constraints", cols, rows, vals, n)
+            try:
+                h.ctx.inject_at(h.A, index, [bit])
+                y, want = h.spmv(x), o.spmv(x)
+                ev, fatal = h.take_events()
+                assert (ev, fatal) == o.events(), (index, bit)
+                fatal_seen += fatal
+                if not fatal and not coo_col_moved(o, index, cols):
+                    assert bits_equal(y, want), (index, bit)
+            finally:
+                h.close()
+    assert fatal_seen > 20
+
+
+def test_shard_geometry_and_global_event_index(amd):
+    """Row-block shard: n_out local rows, columns index a longer vector, events
+    carry index_base + local element index."""
+    cols, rows, vals, n = random_spd(200, 8, seed=6)
+    r0, r1 = 60, 130
+    m = (rows >= r0) & (rows < r1)
+    base = int(np.argmax(m))
+    x = rhs(n, 8)
+    for fmt in (CSR,):
+        o = OracleMatrix(fmt, "secded", cols[m], rows[m] - r0, vals[m], r1 - r0, n_in=n, index_base=base)
+        h = Hip(amd, fmt, "secded", cols[m], rows[m] - r0, vals[m], r1 - r0, n_in=n, index_base=base)
+        try:
+            o.inject(17, [3])
+            h.ctx.inject_at(h.A, 17, [3])
+            y, want = h.spmv(x), o.spmv(x)
+            ev, fatal = h.take_events()
+            assert (ev, fatal) == o.events() and ev[0][1] == base + 17
+            assert bits_equal(y, want)
+        finally:
+            h.close()
+
+
+def test_create_rejects_bad_input(amd):
+    ctx = amd.HIPContext("sed", "csr", on_event=lambda e, f: None)
+    try:
+        one = np.array([1.0])
+        with pytest.raises(amd.AbftError) as e:  # column needs more than 24 bits under ECC
+            ctx.create_matrix(np.array([1 << 24], np.uint32), np.array([0], np.uint32), one, 1 << 25, 1)
+        assert e.value.code == -4
+        with pytest.raises(amd.AbftError):  # row outside the matrix
+            ctx.create_matrix(np.array([0], np.uint32), np.array([7], np.uint32), one, 4, 1)
+        with pytest.raises(amd.AbftError):  # rows not sorted
+            ctx.create_matrix(np.array([0, 0], np.uint32), np.array([1, 0], np.uint32), np.array([1.0, 1.0]), 4, 2)
+        A = ctx.create_matrix(np.array([0], np.uint32), np.array([0], np.uint32), one, 4, 1)
+        v3, v4 = ctx.create_vector(3), ctx.create_vector(4)
+        with pytest.raises(amd.AbftError):  # vector shorter than the matrix: refused on the host
+            ctx.spmv(A, v3, v4)
+        with pytest.raises(amd.AbftError):
+            ctx.inject_at(A, 5, [1])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 255, 1000, 4097, 1 << 20, (1 << 20) + 3])
+def test_vector_kernels(amd, n):
+    ctx = amd.HIPContext("none", "csr")
+    rng = np.random.default_rng(n)
+    try:
+        a, b, p, w = (rng.standard_normal(n) for _ in range(4))
+        va, vb, vp, vw = (ctx.create_vector(n) for _ in range(4))
+        for v, arr in ((va, a), (vb, b), (vp, p), (vw, w)):
+            ctx.upload(v, arr)
+        d = ctx.dot(va, vb)
+        ref = ora_dot(a, b)
+        scale = float(np.abs(a * b).sum())
+        assert abs(d - ref) <= 1e-13 * scale
+        x_ref, r_ref = a.copy(), b.copy()
+        rr_ref = ora_calc_xr(x_ref, r_ref, p, w, 0.37)
+        rr = ctx.calc_xr(va, vb, vp, vw, 0.37)
+        assert abs(rr - rr_ref) <= 1e-13 * float((r_ref * r_ref).sum())
+        assert bits_equal(ctx.download(va), x_ref) and bits_equal(ctx.download(vb), r_ref)
+        p_ref = p.copy()
+        ora_calc_p(p_ref, r_ref, 1.7)
+        ctx.calc_p(vp, vb, 1.7)
+        assert bits_equal(ctx.download(vp), p_ref)
+        ctx.copy_vector(vw, vp)
+        assert bits_equal(ctx.download(vw), p_ref)
+        # same call twice: reductions are deterministic
+        assert ctx.dot(va, vb) == ctx.dot(va, vb)
+        if n > 8:  # an odd-offset window: the unaligned (scalar) kernels
+            wa, wb = ctx.view_vector(va, 1, n - 3), ctx.view_vector(vb, 1, n - 3)
+            d2 = ctx.dot(wa, wb)
+            assert abs(d2 - ora_dot(x_ref[1:n - 2], r_ref[1:n - 2])) <= 1e-13 * float(np.abs(x_ref * r_ref).sum())
+            ctx.calc_p(wa, wb, -0.5)
+            e = x_ref.copy()
+            ora_calc_p(e[1:n - 2], r_ref[1:n - 2], -0.5)
+            assert bits_equal(ctx.download(va), e)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("mode", MODES)
+def test_cg_iteration_count_and_residual_history(amd, fmt, mode):
+    cols, rows, vals, n = laplace5(64, 64)
+    b = rhs(n, 1)
+    o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+    it_o, hist_o, x_o, _ = o.cg(b)
+    ctx = amd.HIPContext(mode, FNAME[fmt])
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        vb, vx, vr, vp, vw = (ctx.create_vector(n) for _ in range(5))
+        ctx.upload(vb, b)
+        ctx.upload(vx, np.zeros(n))
+        hist = []
+        it, rr = amd.cg_solve(ctx, A, vb, vx, vr, vp, vw, on_iteration=lambda i, r: hist.append(r))
+        assert it == it_o and it > 50
+        assert np.allclose(hist, hist_o, rtol=1e-10, atol=0)
+        x = ctx.download(vx)
+        assert np.abs(x - x_o).max() <= 1e-10 * np.abs(x_o).max()
+    finally:
+        ctx.close()
+
+
+def test_golden_vectors(amd):
+    """The reference's own outputs (tests/golden/kernels.npz, flips.json)."""
+    kern = np.load(os.path.join(G, "kernels.npz"))
+    for mat in ("lap9x7", "rnd80", "lap16"):
+        cols, rows, vals = kern[mat + "_cols"], kern[mat + "_rows"], kern[mat + "_vals"]
+        n = int(kern[mat + "_n"][0])
+        for fmt in FMTS:
+            for mode in MODES:
+                key = "%s_%s_%s" % (mat, FNAME[fmt], mode)
+                h = Hip(amd, fmt, mode, cols, rows, vals, n)
+                try:
+                    assert np.array_equal(h.ctx.stored_words(h.A), kern[key + "_words"]), key
+                    assert bits_equal(h.spmv(kern[mat + "_x"]), kern[key + "_y"]), key
+                finally:
+                    h.close()
+    cases = json.load(open(os.path.join(G, "flips.json")))
+    for c in cases:
+        mat, fmt = c["matrix"], {"csr": CSR, "coo": COO}[c["fmt"]]
+        n = int(kern[mat + "_n"][0])
+        h = Hip(amd, fmt, c["mode"], kern[mat + "_cols"], kern[mat + "_rows"], kern[mat + "_vals"], n)
+        try:
+            h.ctx.inject_at(h.A, c["index"], c["bits"])
+            x = kern[mat + "_x"]
+            y1 = h.spmv(x)
+            ev, fatal = h.take_events()
+            text = "".join(event_lines(ev, fmt))
+            assert fatal == (c["exit"] == 1), c
+            if fatal:
+                assert text == c["stdout"], c
+                continue
+            y2 = h.spmv(x)
+            ev2, _ = h.take_events()
+            assert text + "".join(event_lines(ev2, fmt)) == c["stdout"], c
+            if not (fmt == COO and (c["words_after"][0][0] & 0xFFFFFF) != int(kern[mat + "_cols"][c["index"]])):
+                assert [format(int(v), "016x") for v in y1.view(np.uint64)] == c["y1"], c
+                assert [format(int(v), "016x") for v in y2.view(np.uint64)] == c["y2"], c
+            assert [int(v) for v in h.ctx.stored_words(h.A)[c["index"]]] == c["words_after"][0], c
+        finally:
+            h.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_inject_bitflip_draws_like_reference(amd, fmt, capfd):
+    """-x: same libc rand() sequence as inject_bitflip (1 + num_flips draws)."""
+    libc = ctypes.CDLL(None)
+    cols, rows, vals, n = random_spd(64, 6, seed=12)
+    for kind, name in ((0, "ANY"), (1, "VALUE"), (2, "INDEX")):
+        for flips in (1, 2, 3):
+            libc.srand(4321)
+            o = OracleMatrix(fmt, "none", cols, rows, vals, n)
+            idx, bits = o.inject_rand(kind, flips)
+            ctx = amd.HIPContext("none", FNAME[fmt])
+            try:
+                A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+                libc.srand(4321)
+                capfd.readouterr()
+                got = ctx.inject_bitflip(A, name, flips)
+                out = capfd.readouterr().out
+                assert got == (idx, bits)
+                assert out == "".join("*** flipping bit %d at index %d ***\n" % (b, idx) for b in bits)
+                assert np.array_equal(ctx.stored_words(A), o.stored_words())
+            finally:
+                ctx.close()
+
+
+def test_fatal_event_prints_reference_line_and_exits(amd, capfd):
+    cols, rows, vals, n = laplace5(16, 16)
+    ctx = amd.HIPContext("sed", "csr")
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        vb, vx, vr, vp, vw = (ctx.create_vector(n) for _ in range(5))
+        ctx.upload(vb, rhs(n, 1))
+        ctx.upload(vx, np.zeros(n))
+        ctx.inject_at(A, 123, [70])
+        with pytest.raises(SystemExit) as e:
+            amd.cg_solve(ctx, A, vb, vx, vr, vp, vw)
+        assert e.value.code == 1
+        assert capfd.readouterr().out == "[ECC] error detected at index 123\n"
+    finally:
+        ctx.close()

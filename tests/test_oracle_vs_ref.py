@@ -7,7 +7,7 @@ import pytest
 
 from _capture import run_captured
 from _oracle import (COO, CSR, MODES, Oracle, OracleMatrix, Ref, event_lines, have_ref, laplace5,
-                     ora_calc_p, ora_calc_xr, ora_dot, random_spd, rhs)
+                     ora_calc_p, ora_calc_xr, ora_dot, random_spd, ref_cg, ref_flip_spmv, ref_inject_rand, rhs)
 
 pytestmark = [pytest.mark.ref, pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built")]
 
@@ -60,23 +60,15 @@ def test_encoded_matrix_identical(fmt, mode):
 @pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("mode", MODES)
 def test_spmv_bit_identical_no_faults(fmt, mode):
-    for cols, rows, vals, n in (laplace5(9, 7), random_spd(80, 8, seed=5)):
+    for mat in (laplace5(9, 7), random_spd(80, 8, seed=5)):
+        cols, rows, vals, n = mat
         x = rhs(n, 11) - 0.5
         o = OracleMatrix(fmt, mode, cols, rows, vals, n)
-        r = Ref(fmt, mode, cols, rows, vals, n)
-        code, text, y_ref = run_captured(r.spmv, x)
+        code, text, ((y_ref,), _) = run_captured(ref_flip_spmv, fmt, mode, mat, 0, [], x, 1)
         assert code == 0 and text == ""
         y = o.spmv(x)
         assert np.array_equal(y.view(np.uint64), y_ref.view(np.uint64))
         assert o.events() == ([], False)
-
-
-def _ref_flip_spmv(fmt, mode, mat, index, bits, x, passes=2):
-    cols, rows, vals, n = mat
-    r = Ref(fmt, mode, cols, rows, vals, n)
-    r.flip(index, bits)
-    ys = [r.spmv(x) for _ in range(passes)]
-    return ys, r.stored_words()
 
 
 @pytest.mark.parametrize("fmt", FMTS)
@@ -87,7 +79,7 @@ def test_every_single_flip_same_events_and_result(fmt, mode):
     x = rhs(n, 2) + 0.25
     index = len(vals) // 2
     for bit in range(NBITS[fmt]):
-        code, text, res = run_captured(_ref_flip_spmv, fmt, mode, mat, index, [bit], x)
+        code, text, res = run_captured(ref_flip_spmv, fmt, mode, mat, index, [bit], x)
         o = OracleMatrix(fmt, mode, cols, rows, vals, n)
         o.inject(index, [bit])
         y1 = o.spmv(x)
@@ -118,7 +110,7 @@ def test_double_flips_same_behaviour(fmt, mode):
     for _ in range(60):
         b1, b2 = rng.choice(NBITS[fmt], size=2, replace=False)
         # a double flip that changes the gather index beyond the vector is UB in the reference
-        code, text, res = run_captured(_ref_flip_spmv, fmt, mode, mat, index, [b1, b2], x, 1)
+        code, text, res = run_captured(ref_flip_spmv, fmt, mode, mat, index, [b1, b2], x, 1)
         o = OracleMatrix(fmt, mode, cols, rows, vals, n)
         o.inject(index, [b1, b2])
         y = o.spmv(x)
@@ -141,7 +133,7 @@ def test_constraints_violations_match(fmt):
     hit = 0
     for index in (0, 5, len(vals) - 1, len(vals) // 3):
         for bit in idx_bits:
-            code, text, res = run_captured(_ref_flip_spmv, fmt, "constraints", mat, index, [bit], x, 1)
+            code, text, res = run_captured(ref_flip_spmv, fmt, "constraints", mat, index, [bit], x, 1)
             if code not in (0, 1):
                 continue  # reference faulted on an out-of-range gather before any check fired
             o = OracleMatrix(fmt, "constraints", cols, rows, vals, n)
@@ -175,12 +167,12 @@ def test_vector_kernels_bit_identical():
 @pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("mode", MODES)
 def test_cg_history_bit_identical(fmt, mode):
-    cols, rows, vals, n = laplace5(16, 16)
+    mat = laplace5(16, 16)
+    cols, rows, vals, n = mat
     b = rhs(n, 1)
     o = OracleMatrix(fmt, mode, cols, rows, vals, n)
-    r = Ref(fmt, mode, cols, rows, vals, n)
     it_o, h_o, x_o, fatal = o.cg(b)
-    code, text, (it_r, h_r, x_r) = run_captured(r.cg, b)
+    code, text, (it_r, h_r, x_r) = run_captured(ref_cg, fmt, mode, mat, b)
     assert code == 0 and not fatal
     assert it_o == it_r and it_o > 10
     assert np.array_equal(h_o.view(np.uint64), h_r.view(np.uint64))
@@ -195,16 +187,9 @@ def test_inject_rand_draws_like_reference(fmt):
     mat = random_spd(30, 6, seed=12)
     cols, rows, vals, n = mat
 
-    def ref_side(kind, flips):
-        libc.srand(1234)
-        r = Ref(fmt, "none", cols, rows, vals, n)
-        r.L.ref_inject_rand(r.ctx, r.mat, kind, flips)
-        r.L.ref_flush()
-        return r.stored_words()
-
     for kind in (0, 1, 2):
         for flips in (1, 2, 3):
-            code, text, words = run_captured(ref_side, kind, flips)
+            code, text, words = run_captured(ref_inject_rand, fmt, mat, 1234, kind, flips)
             assert code == 0
             libc.srand(1234)
             o = OracleMatrix(fmt, "none", cols, rows, vals, n)
