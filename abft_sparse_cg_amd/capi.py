@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabft_hip.so")
+LIB_PATH = os.environ.get("ABFT_HIP_LIB") or os.path.join(_HERE, "libabft_hip.so")  # override: A/B builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "abft_hip.h")
 
 OK = 0

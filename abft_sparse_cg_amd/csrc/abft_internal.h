@@ -38,10 +38,24 @@ struct CooDev {
 
 #define ABFT_COLMASK_HOST 0x00FFFFFFu
 
+// Tuning knobs (overridable with -D for A/B builds; defaults are the measured best)
+#ifndef ABFT_CFG_CSR_EPT
+#define ABFT_CFG_CSR_EPT 4
+#endif
+#ifndef ABFT_CFG_COO_EPT
+#define ABFT_CFG_COO_EPT 4
+#endif
+#ifndef ABFT_CFG_NT
+#define ABFT_CFG_NT 1  // stream cols/vals with the non-temporal hint
+#endif
+#ifndef ABFT_CFG_XCD
+#define ABFT_CFG_XCD 1  // XCD-aware tile order
+#endif
+
 constexpr int ABFT_BLOCK = 256;
-constexpr int ABFT_CSR_EPT = 4;                          // elements per thread per tile
+constexpr int ABFT_CSR_EPT = ABFT_CFG_CSR_EPT;           // elements per thread per tile
 constexpr int ABFT_CSR_TILE = ABFT_BLOCK * ABFT_CSR_EPT;  // nnz staged per block
-constexpr int ABFT_COO_EPT = 4;
+constexpr int ABFT_COO_EPT = ABFT_CFG_COO_EPT;
 constexpr int ABFT_COO_TILE = ABFT_BLOCK * ABFT_COO_EPT;
 constexpr int ABFT_MAX_PARTIALS = 2048;  // reduction blocks (256 CUs x 8)
 

@@ -17,6 +17,12 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+#if ABFT_CFG_NT
+#define STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define STREAM_LOAD(p) (*(p))
+#endif
+
 // ------------------------------------------------------------------ helpers --
 
 // Hardware deals consecutive workgroup ids round-robin over the 8 XCDs
@@ -24,6 +30,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // range of tiles so the x-window its blocks gather from stays in that XCD's L2
 // (speed only; the map is a bijection for every nblk).
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nblk) {
+#if !ABFT_CFG_XCD
+  return b;
+#endif
   const uint32_t xcd = b & 7u, q = nblk >> 3, r = nblk & 7u;
   const uint32_t first = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
   return first + (b >> 3);
@@ -37,10 +46,6 @@ __device__ __forceinline__ void push_event(const EventRing &ev, uint32_t kind, u
     e.kind = kind; e.index = index; e.bit = bit; e.fmt = fmt;
     ev.buf[slot] = e;
   }
-}
-
-__device__ __forceinline__ double gather_x(const double *__restrict__ x, uint32_t idx, uint32_t n) {
-  return idx < n ? x[idx] : 0.0;  // a corrupted index must never fault the GPU
 }
 
 __device__ __forceinline__ double as_double(uint32_t lo, uint32_t hi) {
@@ -152,36 +157,16 @@ hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s
 
 // ----------------------------------------------------------------- CSR SpMV --
 
-// One element of the load phase: ECC check (+ repair and write-back), column
-// mask, gather, multiply.  Returns the product.
-template <int MODE>
-__device__ __forceinline__ double csr_element(const CsrDev &A, const double *__restrict__ x,
-                                              const EventRing &ev, uint32_t i, uint32_t lo,
-                                              uint32_t hi, uint32_t c, uint32_t &col_out) {
-  uint32_t w[3] = {lo, hi, c};
-  if (MODE >= MODE_SED) {
-    if (__builtin_expect(ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
-      EccWords<FMT_CSR> e;
-      e.w[0] = w[0]; e.w[1] = w[1]; e.w[2] = w[2]; e.rc = 0;
-      e = ecc_cold<FMT_CSR, MODE>(e, A.index_base + i, ev);
-      w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2];
-      if (e.rc > 0) {  // reference CSR/CPUContext.cpp:275-276, 333-334, 389-390
-        A.vals[i] = as_double(w[0], w[1]);
-        A.cols[i] = w[2];
-      } else {
-        col_out = 0xFFFFFFFFu;
-        return 0.0;
-      }
-    }
-    w[2] &= ABFT_COLMASK;  // reference CSR/CPUContext.cpp:238, 282, 338, 404
-  }
-  col_out = w[2];
-  return as_double(w[0], w[1]) * gather_x(x, w[2], A.n_in);
-}
-
 // Load phase of one tile: elements [lo, hi) of the matrix, staged at LDS slot
-// (i - base); base is even so every thread's pair load is 16-byte aligned.
-// Each wave instruction streams 1 KiB of vals and 512 B of cols, contiguous.
+// (i - base); base is even so every thread's pair load is 16-byte aligned and a
+// wave instruction streams 1 KiB of vals / 512 B of cols, contiguous.
+//
+// Written branch-free on purpose: every lane issues all its loads (an
+// out-of-tile lane re-reads the tile's first pair), then all its gathers
+// (index clamped to 0 when out of range), then multiplies and selects.  With
+// per-element `if`s hipcc puts an s_waitcnt vmcnt(0) at every join and the four
+// gathers of a thread run one after the other.  The only branch left is the
+// ECC cold path, taken when an element fails its check.
 template <int MODE, int EPT>
 __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restrict__ x,
                                           const EventRing &ev, uint32_t base, uint32_t lo,
@@ -192,27 +177,53 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
     const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
-    if (i < hi) {  // the arrays are over-allocated by 2: i+1 == hi is still in bounds
-      v[s] = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(A.vals + i));
-      c[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(A.cols + i));
+    const uint32_t ii = i < hi ? i : base;  // always a valid, even element index
+    v[s] = STREAM_LOAD(reinterpret_cast<const f64x2 *>(A.vals + ii));
+    c[s] = STREAM_LOAD(reinterpret_cast<const u32x2 *>(A.cols + ii));
+  }
+  uint32_t col[EPT];
+  double val[EPT];
+  bool ok[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; j++) {
+    const int s = j >> 1;
+    const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK) + (uint32_t)(j & 1);
+    const double d = (j & 1) ? v[s].y : v[s].x;
+    uint32_t w[3] = {(uint32_t)__double2loint(d), (uint32_t)__double2hiint(d), (j & 1) ? c[s].y : c[s].x};
+    bool valid = i >= lo && i < hi;
+    if (MODE >= MODE_SED) {
+      if (__builtin_expect(valid && ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
+        EccWords<FMT_CSR> e;
+        e.w[0] = w[0]; e.w[1] = w[1]; e.w[2] = w[2]; e.rc = 0;
+        e = ecc_cold<FMT_CSR, MODE>(e, A.index_base + i, ev);
+        w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2];
+        if (e.rc > 0) {  // reference CSR/CPUContext.cpp:275-276, 333-334, 389-390
+          A.vals[i] = as_double(w[0], w[1]);
+          A.cols[i] = w[2];
+        } else {
+          valid = false;  // fatal: the reference never uses this element
+        }
+      }
+      w[2] &= ABFT_COLMASK;  // reference CSR/CPUContext.cpp:238, 282, 338, 404
     }
+    col[j] = w[2];
+    val[j] = as_double(w[0], w[1]);
+    ok[j] = valid;
+  }
+  double xv[EPT];
+#pragma unroll
+  for (int j = 0; j < EPT; j++) {
+    const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
+    xv[j] = x[in ? col[j] : 0u];
+    xv[j] = in ? xv[j] : 0.0;
   }
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
     const uint32_t k = 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
-    const uint32_t i = base + k;
-    if (i < hi) {
-      double p0 = 0.0, p1 = 0.0;
-      uint32_t c0 = 0, c1 = 0;
-      if (i >= lo)
-        p0 = csr_element<MODE>(A, x, ev, i, (uint32_t)__double2loint(v[s].x),
-                               (uint32_t)__double2hiint(v[s].x), c[s].x, c0);
-      if (i + 1u < hi)
-        p1 = csr_element<MODE>(A, x, ev, i + 1u, (uint32_t)__double2loint(v[s].y),
-                               (uint32_t)__double2hiint(v[s].y), c[s].y, c1);
-      *reinterpret_cast<double2 *>(s_prod + k) = make_double2(p0, p1);
-      if (MODE == MODE_CONSTRAINTS) *reinterpret_cast<uint2 *>(s_col + k) = make_uint2(c0, c1);
-    }
+    const double p0 = val[2 * s] * xv[2 * s], p1 = val[2 * s + 1] * xv[2 * s + 1];
+    *reinterpret_cast<double2 *>(s_prod + k) = make_double2(ok[2 * s] ? p0 : 0.0, ok[2 * s + 1] ? p1 : 0.0);
+    if (MODE == MODE_CONSTRAINTS)
+      *reinterpret_cast<uint2 *>(s_col + k) = make_uint2(col[2 * s], col[2 * s + 1]);
   }
 }
 
@@ -224,21 +235,34 @@ __device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev
                                             uint32_t rs, uint32_t re, uint32_t row_end,
                                             const double *s_prod, const uint32_t *s_col,
                                             double &acc) {
+  if (MODE != MODE_CONSTRAINTS) {
+    // four LDS reads in flight, then up to four adds in element order; a lane
+    // past its row's end re-reads its last slot and skips the add (no "+ 0.0":
+    // that could turn a -0.0 sum into +0.0)
+    for (uint32_t i = rs; i < re; i += 4u) {
+      const uint32_t k = i - base, last = re - 1u - base;
+      const double a0 = s_prod[k], a1 = s_prod[min(k + 1u, last)], a2 = s_prod[min(k + 2u, last)],
+                   a3 = s_prod[min(k + 3u, last)];
+      acc += a0;
+      if (i + 1u < re) acc += a1;
+      if (i + 2u < re) acc += a2;
+      if (i + 3u < re) acc += a3;
+    }
+    return true;
+  }
   for (uint32_t i = rs; i < re; i++) {
     const uint32_t k = i - base;
-    if (MODE == MODE_CONSTRAINTS) {
-      const uint32_t col = s_col[k];
-      if (col >= A.n_in) {
-        push_event(ev, ABFT_EV_COL_SIZE, A.index_base + i, 0, FMT_CSR);
+    const uint32_t col = s_col[k];
+    if (col >= A.n_in) {
+      push_event(ev, ABFT_EV_COL_SIZE, A.index_base + i, 0, FMT_CSR);
+      return false;
+    }
+    if (i + 1u < row_end) {
+      // the next column is in the tile unless this is the last staged element
+      const uint32_t nxt = (i + 1u < re) ? s_col[k + 1u] : A.cols[i + 1u];
+      if (nxt <= col) {
+        push_event(ev, ABFT_EV_COL_ORDER, A.index_base + i, 0, FMT_CSR);
         return false;
-      }
-      if (i + 1u < row_end) {
-        // the next column is in the tile unless this is the last staged element
-        const uint32_t nxt = (i + 1u < re) ? s_col[k + 1u] : A.cols[i + 1u];
-        if (nxt <= col) {
-          push_event(ev, ABFT_EV_COL_ORDER, A.index_base + i, 0, FMT_CSR);
-          return false;
-        }
       }
     }
     acc += s_prod[k];
@@ -344,39 +368,69 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
-    if (j < hi) e[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(A.elems + j));
+    e[s] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
   }
+  uint32_t row[EPT];
+  double val[EPT];
+  bool ok[EPT];
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
-    const uint32_t k = threadIdx.x + (uint32_t)s * ABFT_BLOCK;
-    const uint32_t j = lo + k;
-    if (j >= hi) continue;
+    const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
     uint32_t w[4] = {e[s].x, e[s].y, e[s].z, e[s].w};
-    double prod = 0.0;
-    bool dead = false;
+    bool valid = j < hi;
     if (MODE == MODE_CONSTRAINTS) {
-      const uint32_t i = A.orig_index[j];
-      const uint32_t gi = A.index_base + i;
-      if (w[1] >= A.n_in) { push_event(ev, ABFT_EV_ROW_SIZE, gi, 0, FMT_COO); dead = true; }
-      else if (w[0] >= A.n_out) { push_event(ev, ABFT_EV_COL_SIZE, gi, 0, FMT_COO); dead = true; }
-      else if (i + 1u < A.nnz) {
-        const uint4 nx = A.elems[A.pos_of_orig[i + 1u]];
-        if (w[1] > nx.y) { push_event(ev, ABFT_EV_ROW_ORDER, gi, 0, FMT_COO); dead = true; }
-        else if (w[1] == nx.y && w[0] >= nx.x) { push_event(ev, ABFT_EV_COL_ORDER, gi, 0, FMT_COO); dead = true; }
+      if (valid) {  // per-element structural checks: a cold, gather-heavy mode by nature
+        const uint32_t i = A.orig_index[j];
+        const uint32_t gi = A.index_base + i;
+        if (w[1] >= A.n_in) { push_event(ev, ABFT_EV_ROW_SIZE, gi, 0, FMT_COO); valid = false; }
+        else if (w[0] >= A.n_out) { push_event(ev, ABFT_EV_COL_SIZE, gi, 0, FMT_COO); valid = false; }
+        else if (i + 1u < A.nnz) {
+          const uint4 nx = A.elems[A.pos_of_orig[i + 1u]];
+          if (w[1] > nx.y) { push_event(ev, ABFT_EV_ROW_ORDER, gi, 0, FMT_COO); valid = false; }
+          else if (w[1] == nx.y && w[0] >= nx.x) { push_event(ev, ABFT_EV_COL_ORDER, gi, 0, FMT_COO); valid = false; }
+        }
       }
     } else if (MODE >= MODE_SED) {
-      if (__builtin_expect(ecc_suspect<FMT_COO, MODE>(w) != 0, 0)) {
+      if (__builtin_expect(valid && ecc_suspect<FMT_COO, MODE>(w) != 0, 0)) {
         EccWords<FMT_COO> ce;
         ce.w[0] = w[0]; ce.w[1] = w[1]; ce.w[2] = w[2]; ce.w[3] = w[3]; ce.rc = 0;
         ce = ecc_cold<FMT_COO, MODE>(ce, A.index_base + A.orig_index[j], ev);
         w[0] = ce.w[0]; w[1] = ce.w[1]; w[2] = ce.w[2]; w[3] = ce.w[3];
         if (ce.rc > 0) A.elems[j] = make_uint4(w[0], w[1], w[2], w[3]);  // COO/CPUContext.cpp:255, 310, 364
-        else dead = true;
+        else valid = false;
       }
     }
-    if (!dead) prod = as_double(w[2], w[3]) * gather_x(x, w[1], A.n_in);
-    s_prod[k] = prod;
+    row[s] = w[1];
+    val[s] = as_double(w[2], w[3]);
+    ok[s] = valid;
   }
+  double xv[EPT];
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const bool in = ok[s] && row[s] < A.n_in;
+    xv[s] = x[in ? row[s] : 0u];
+    xv[s] = in ? xv[s] : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const double p = val[s] * xv[s];
+    s_prod[threadIdx.x + (uint32_t)s * ABFT_BLOCK] = ok[s] ? p : 0.0;
+  }
+}
+
+// ordered sum of LDS slots [a, b): four reads in flight, adds in slot order
+__device__ __forceinline__ double lds_ordered_sum(const double *s_prod, uint32_t a, uint32_t b) {
+  double acc = 0.0;
+  for (uint32_t k = a; k < b; k += 4u) {
+    const uint32_t last = b - 1u;
+    const double a0 = s_prod[k], a1 = s_prod[min(k + 1u, last)], a2 = s_prod[min(k + 2u, last)],
+                 a3 = s_prod[min(k + 3u, last)];
+    acc += a0;
+    if (k + 1u < b) acc += a1;
+    if (k + 2u < b) acc += a2;
+    if (k + 3u < b) acc += a3;
+  }
+  return acc;
 }
 
 // COO SpMV, all modes: result[col] += value * vec[row] (reference
@@ -401,9 +455,8 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
     __syncthreads();
     for (uint32_t grp = g; grp < g1; grp += ABFT_BLOCK) {
       if (grp != g) { gs = A.grp_ptr[grp]; ge = A.grp_ptr[grp + 1]; }
-      double acc = 0.0;  // reference zero-fills result first (COO/CPUContext.cpp:108-109)
-      for (uint32_t j = gs; j < ge; j++) acc += s_prod[j - e0];
-      y[grp] = acc;
+      // reference zero-fills result first (COO/CPUContext.cpp:108-109)
+      y[grp] = lds_ordered_sum(s_prod, gs - e0, ge - e0);
     }
     return;
   }

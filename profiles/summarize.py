@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output into the per-kernel summaries kept under profiles/.
+
+    python profiles/summarize.py trace  <dir> <out.md>      # --kernel-trace --stats run
+    python profiles/summarize.py pmc    <dir> <out.json>    # one --pmc run (any counters)
+
+trace: per kernel name, launches / total / average / min / max duration (ns from
+the kernel-trace CSV's Start_Timestamp / End_Timestamp).
+pmc:   per kernel name and counter, the average value per launch.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("void ", "").replace(" [clone .kd]", "").replace(".kd", "")
+    return name.strip()
+
+
+def find(d, pattern):
+    return sorted(glob.glob(os.path.join(d, "**", pattern), recursive=True))
+
+
+def trace(d, out):
+    rows = defaultdict(list)
+    for f in find(d, "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            rows[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    tot = sum(sum(v) for v in rows.values()) or 1
+    with open(out, "w") as o:
+        o.write("| kernel | launches | total ms | avg us | min us | max us | % |\n|---|---|---|---|---|---|---|\n")
+        for k, v in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+            o.write("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.1f |\n" % (
+                k, len(v), sum(v) / 1e6, sum(v) / len(v) / 1e3, min(v) / 1e3, max(v) / 1e3, 100.0 * sum(v) / tot))
+    print(open(out).read())
+
+
+def pmc(d, out):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    res = {k: {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()}
+           for k, cs in acc.items()}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for k, cs in res.items():
+        for c, v in cs.items():
+            print("%-60s %-18s %14.1f  (%d launches)" % (k[:60], c, v["avg_per_launch"], v["launches"]))
+
+
+if __name__ == "__main__":
+    {"trace": trace, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
