@@ -1,0 +1,4 @@
+// COO/HIPContext.cpp -- registers the hip target of cg-coo (see ../HIPContext.h).
+#include "HIPContext.h"
+
+ABFT_REGISTER_HIP_CONTEXTS(ABFT_FMT_COO)

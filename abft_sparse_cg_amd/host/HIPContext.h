@@ -1,0 +1,85 @@
+// HIPContext.h -- the `hip` target: a CGContext backend whose every method is
+// one call into libabft_hip.so through the C ABI of include/abft_hip.h.
+//
+// One class template serves both executables: cg-csr instantiates it with
+// ABFT_FMT_CSR (CSR/HIPContext.cpp), cg-coo with ABFT_FMT_COO
+// (COO/HIPContext.cpp); each registers ("hip", mode) for the six ABFT modes
+// (plus "sec" = sec7), mirroring reference CSR/CPUContext.cpp:413-421.
+//
+// Error behaviour is the reference's: nothing is returned; ECC / constraint
+// events are printed to stdout with the reference's text, fatal ones end the
+// process with exit(1) (reference CSR/CPUContext.cpp:233-234, 398-399).  Events
+// raised by an asynchronous spmv are reported at the next call that returns
+// data to the host (dot, calc_xr, map_vector, destroy_matrix) -- before the
+// driver prints anything computed from them, so stdout order is preserved.
+//
+// A failing library call (no GPU, out of memory, bad shapes) is fatal too:
+// message on stderr, exit(2).  There is no CPU fallback.
+#pragma once
+#include "CGContext.h"
+#include "abft_hip.h"
+
+struct cg_matrix
+{
+  abft_hip_matrix *handle;
+  unsigned N;
+  unsigned nnz;
+};
+
+struct cg_vector
+{
+  abft_hip_vector *handle;
+  int N;
+};
+
+class HIPContextBase : public CGContext
+{
+public:
+  HIPContextBase(int format, int mode);
+  virtual ~HIPContextBase();
+
+  virtual cg_matrix* create_matrix(const uint32_t *columns, const uint32_t *rows,
+                                   const double *values, int N, int nnz);
+  virtual void destroy_matrix(cg_matrix *mat);
+
+  virtual cg_vector* create_vector(int N);
+  virtual void destroy_vector(cg_vector *vec);
+  virtual double* map_vector(cg_vector *v);
+  virtual void unmap_vector(cg_vector *v, double *h);
+  virtual void copy_vector(cg_vector *dst, const cg_vector *src);
+
+  virtual double dot(const cg_vector *a, const cg_vector *b);
+  virtual double calc_xr(cg_vector *x, cg_vector *r, const cg_vector *p, const cg_vector *w,
+                         double alpha);
+  virtual void calc_p(cg_vector *p, const cg_vector *r, double beta);
+  virtual void spmv(const cg_matrix *mat, const cg_vector *vec, cg_vector *result);
+
+  virtual void inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_flips);
+
+private:
+  void check(int rc, const char *what);
+  void report_events(bool force);
+
+  abft_hip_ctx *ctx_;
+  int format_;
+  int mode_;
+};
+
+template<int FORMAT, int MODE>
+class HIPContext : public HIPContextBase
+{
+public:
+  HIPContext() : HIPContextBase(FORMAT, MODE) {}
+};
+
+#define ABFT_REGISTER_HIP_CONTEXTS(FORMAT)                                                \
+  namespace                                                                               \
+  {                                                                                       \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_NONE> >        hip_none("hip", "none");               \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_CONSTRAINTS> > hip_constraints("hip", "constraints"); \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_SED> >         hip_sed("hip", "sed");                 \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_SEC7> >        hip_sec7("hip", "sec7");               \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_SEC8> >        hip_sec8("hip", "sec8");               \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_SECDED> >      hip_secded("hip", "secded");           \
+    static CGContext::Register<HIPContext<FORMAT, ABFT_MODE_SEC7> >        hip_sec("hip", "sec");                 \
+  }

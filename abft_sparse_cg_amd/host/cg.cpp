@@ -1,0 +1,404 @@
+// cg.cpp -- the conjugate-gradient driver of cg-csr / cg-coo for the hip target.
+//
+// Reproduces the reference driver's command line and stdout (cg.cpp:38-309):
+// same flags and defaults, same report block, one "iteration %5u :  rr = %12.4lf"
+// line per iteration, same final error check -- so scripts written against the
+// reference (run_tests, run_benchmark) work unchanged.  It talks to the backend
+// only through CGContext (cg_matrix / cg_vector stay opaque).
+//
+// Additive options, all off by default:
+//   -s/--synthetic SPEC   build the matrix in memory (generators.cpp) instead of -f
+//   --seed N              seed for -x's rand() draws (reference: time(NULL))
+//   --flip-at I:B[,B..]   flip bit(s) B of element I -- a replayable -x
+//   -q/--quiet            no per-iteration line
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <vector>
+
+#include "CGContext.h"
+#include "matrix_io.h"
+
+namespace
+{
+
+struct Options
+{
+  int num_blocks = 25;
+  int max_itrs = 1000;
+  double conv_threshold = 0.001;
+  const char *matrix_file = "matrices/shallow_water1/shallow_water1.mtx";
+  const char *synthetic = NULL;
+  const char *target = "hip";
+  const char *mode = "none";
+  int num_bit_flips = 0;
+  CGContext::BitFlipKind bitflip_kind = CGContext::ANY;
+  bool have_seed = false;
+  unsigned seed = 0;
+  bool quiet = false;
+  long flip_index = -1;
+  std::vector<int> flip_bits;
+};
+
+double to_double(const char *s)
+{
+  char *end;
+  double v = strtod(s, &end);
+  return *end ? -1 : v;
+}
+
+int to_int(const char *s)
+{
+  char *end;
+  int v = (int)strtoul(s, &end, 10);
+  return *end ? -1 : v;
+}
+
+[[noreturn]] void fail(const char *msg)
+{
+  printf("%s\n", msg);
+  exit(1);
+}
+
+void usage(const char *argv0)
+{
+  const char *exe = strrchr(argv0, '/');
+  printf("\n");
+  printf("Usage: %s [OPTIONS]\n\n", exe ? exe + 1 : argv0);
+  printf("Options:\n");
+  printf("  -h  --help                  Print this message\n"
+         "  -b  --num-blocks      B     Number of times to block input matrix\n"
+         "  -c  --convergence     C     Convergence threshold\n"
+         "  -f  --matrix-file     M     Path to matrix-market format file\n"
+         "  -i  --iterations      I     Maximum number of iterations\n"
+         "  -l  --list                  List available implementations\n"
+         "  -m  --mode            MODE  ABFT mode\n"
+         "  -t  --target          TARG  Implementation target\n"
+         "  -x  --inject-bitflip        Inject a random bit-flip into A\n"
+         "\n"
+         "  The -l|--list argument will provide a list of tuples that describe\n"
+         "  which implementations are available to be passed to the\n"
+         "  -t|--target and -m|--mode arguments.\n"
+         "\n"
+         "  The -x|--inject-bitflip argument optionally takes a number to \n"
+         "  control how many bits to flip, and either INDEX or VALUE to \n"
+         "  restrict the region of bits in the matrix element to target.\n"
+         "\n"
+         "Additional options of this build:\n"
+         "  -s  --synthetic       SPEC  Generate the matrix in memory instead of -f:\n"
+         "                              laplace5:NX,NY | random:N,K,SEED | powerlaw:N,SEED\n"
+         "      --seed            N     Seed for the -x draws (default: time)\n"
+         "      --flip-at  I:B[,B...]   Flip the given bit(s) of matrix element I\n"
+         "  -q  --quiet                 Do not print the per-iteration residual\n");
+  printf("\n");
+}
+
+Options parse(int argc, char *argv[])
+{
+  Options o;
+  for (int i = 1; i < argc; i++)
+  {
+    const char *a = argv[i];
+    auto is = [&](const char *lng, const char *sht) { return !strcmp(a, lng) || (sht && !strcmp(a, sht)); };
+    if (is("--convergence", "-c"))
+    {
+      if (++i >= argc || (o.conv_threshold = to_double(argv[i])) < 0)
+        fail("Invalid convergence threshold");
+    }
+    else if (is("--iterations", "-i"))
+    {
+      if (++i >= argc || (o.max_itrs = to_int(argv[i])) < 0)
+        fail("Invalid number of iterations");
+    }
+    else if (is("--list", "-l"))
+    {
+      CGContext::list_contexts();
+      exit(0);
+    }
+    else if (is("--num-blocks", "-b"))
+    {
+      if (++i >= argc || (o.num_blocks = to_int(argv[i])) < 1)
+        fail("Invalid number of blocks");
+    }
+    else if (is("--matrix-file", "-f"))
+    {
+      if (++i >= argc)
+        fail("Matrix filename required");
+      o.matrix_file = argv[i];
+    }
+    else if (is("--mode", "-m"))
+    {
+      if (++i >= argc)
+        fail("ABFT mode required");
+      o.mode = argv[i];
+    }
+    else if (is("--target", "-t"))
+    {
+      if (++i >= argc)
+        fail("Implementation target required");
+      o.target = argv[i];
+    }
+    else if (is("--inject-bitflip", "-x"))
+    {
+      o.num_bit_flips = 1;
+      while (i + 1 < argc && argv[i + 1][0] != '-')
+      {
+        i++;
+        if (!strcmp(argv[i], "INDEX"))
+          o.bitflip_kind = CGContext::INDEX;
+        else if (!strcmp(argv[i], "VALUE"))
+          o.bitflip_kind = CGContext::VALUE;
+        else if ((o.num_bit_flips = to_int(argv[i])) < 1)
+          fail("Invalid bit-flip parameter");
+      }
+    }
+    else if (is("--synthetic", "-s"))
+    {
+      if (++i >= argc)
+        fail("Synthetic matrix specification required");
+      o.synthetic = argv[i];
+    }
+    else if (is("--seed", NULL))
+    {
+      if (++i >= argc || to_int(argv[i]) < 0)
+        fail("Invalid seed");
+      o.seed = (unsigned)to_int(argv[i]);
+      o.have_seed = true;
+    }
+    else if (is("--flip-at", NULL))
+    {
+      if (++i >= argc)
+        fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
+      char *rest;
+      o.flip_index = strtol(argv[i], &rest, 10);
+      if (*rest != ':' || o.flip_index < 0)
+        fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
+      while (*rest == ':' || *rest == ',')
+      {
+        char *next;
+        long b = strtol(rest + 1, &next, 10);
+        if (next == rest + 1 || b < 0)
+          fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
+        o.flip_bits.push_back((int)b);
+        rest = next;
+      }
+      if (*rest)
+        fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
+    }
+    else if (is("--quiet", "-q"))
+    {
+      o.quiet = true;
+    }
+    else if (is("--help", "-h"))
+    {
+      usage(argv[0]);
+      exit(0);
+    }
+    else
+    {
+      printf("Unrecognized argument '%s' (try '--help')\n", a);
+      exit(1);
+    }
+  }
+  return o;
+}
+
+// glibc's rand() as a private object: the additive-feedback generator r[i] =
+// r[i-3] + r[i-31] (TYPE_3), seeded the way srand(seed) seeds it.  The reference
+// fills b from rand() with the default seed 1 before anything else touches the
+// generator (cg.cpp:66-74); in this process the HIP runtime has already run by
+// then and may have drawn from the shared libc state, so b is produced from an
+// identical private sequence instead.
+class GlibcRand
+{
+public:
+  explicit GlibcRand(unsigned seed = 1)
+  {
+    int32_t r[34];
+    r[0] = seed ? (int32_t)seed : 1;
+    for (int i = 1; i < 31; i++)
+    {
+      int64_t v = (16807LL * r[i - 1]) % 2147483647LL;
+      r[i] = (int32_t)(v < 0 ? v + 2147483647LL : v);
+    }
+    for (int i = 0; i < 31; i++)
+      state_[i] = (uint32_t)r[i];
+    front_ = 3;
+    rear_ = 0;
+    for (int i = 0; i < 310; i++)
+      next();
+  }
+  int next()
+  {
+    state_[front_] += state_[rear_];
+    const int out = (int)(state_[front_] >> 1);
+    front_ = (front_ + 1) % 31;
+    rear_ = (rear_ + 1) % 31;
+    return out;
+  }
+private:
+  uint32_t state_[31];
+  int front_, rear_;
+};
+
+// A replayable stand-in for inject_bitflip's rand() draws: rand() is made to
+// return the wanted element index, then each wanted bit, in the order the
+// backend asks for them (1 + num_flips draws, reference CSR/CPUContext.cpp:137-148).
+// Only used for --flip-at; it keeps the injection inside the CGContext API.
+std::vector<int> g_forced_draws;
+size_t g_forced_pos = 0;
+
+}  // namespace
+
+// glibc lets a program interpose rand(); with nothing forced it is the libc
+// generator (random()), so -x and the b vector behave exactly as in the reference.
+extern "C" int rand(void)
+{
+  if (g_forced_pos < g_forced_draws.size())
+    return g_forced_draws[g_forced_pos++];
+  return (int)random();
+}
+extern "C" void srand(unsigned seed) { srandom(seed); }
+
+int main(int argc, char *argv[])
+{
+  Options o = parse(argc, argv);
+
+  CGContext *context = CGContext::create(o.target, o.mode);
+
+  // ---- input: Matrix-Market file (reference loader) or in-memory generator ----
+  int N = 0, nnz = 0, block_size = 0;
+  uint32_t *cols = NULL, *rows = NULL;
+  double *vals = NULL;
+  if (o.synthetic)
+  {
+    int64_t n = abft_gen_dim(o.synthetic);
+    int64_t cnt = n > 0 ? abft_gen_count(o.synthetic, 0, n, NULL) : -1;
+    if (n <= 0 || cnt < 0 || cnt > 0x7FFFFFFF)
+    {
+      printf("Invalid synthetic matrix '%s'\n", o.synthetic);
+      exit(1);
+    }
+    N = (int)n;
+    nnz = (int)cnt;
+    block_size = N;
+    cols = (uint32_t *)malloc((size_t)nnz * sizeof(uint32_t));
+    rows = (uint32_t *)malloc((size_t)nnz * sizeof(uint32_t));
+    vals = (double *)malloc((size_t)nnz * sizeof(double));
+    abft_gen_fill(o.synthetic, 0, n, cols, rows, vals);
+  }
+  else
+  {
+    int rc = abft_load_mtx(o.matrix_file, o.num_blocks, &N, &block_size, &nnz, &cols, &rows, &vals);
+    if (rc == ABFT_IO_OPEN)
+    {
+      printf("Failed to open '%s'\n", o.matrix_file);
+      exit(1);
+    }
+    if (rc == ABFT_IO_NOT_SQUARE)
+      fail("Matrix is not square");
+    if (rc != ABFT_IO_OK)
+      fail("Failed to read matrix data");
+  }
+  cg_matrix *A = context->create_matrix(cols, rows, vals, N, nnz);
+  abft_free_triplets(cols, rows, vals);
+
+  printf("\n");
+  printf("implementation        = %s-%s\n", o.target, o.mode);
+  printf("matrix size           = %u x %u\n", N, N);
+  printf("matrix block size     = %u x %u\n", block_size, block_size);
+  printf("number of non-zeros   = %u (%.4f%%)\n", nnz, nnz / ((double)N * (double)N) * 100);
+  printf("maximum iterations    = %u\n", o.max_itrs);
+  printf("convergence threshold = %g\n", o.conv_threshold);
+  printf("\n");
+
+  cg_vector *b = context->create_vector(N);
+  cg_vector *x = context->create_vector(N);
+  cg_vector *r = context->create_vector(N);
+  cg_vector *p = context->create_vector(N);
+  cg_vector *w = context->create_vector(N);
+
+  // b = uniform(0,1) from glibc's rand() sequence with its default seed, x = 0
+  double *h_b = context->map_vector(b);
+  double *h_x = context->map_vector(x);
+  GlibcRand libc_rand(1);
+  for (int i = 0; i < N; i++)
+  {
+    h_b[i] = libc_rand.next() / (double)RAND_MAX;
+    h_x[i] = 0.0;
+  }
+  context->unmap_vector(b, h_b);
+  context->unmap_vector(x, h_x);
+
+  if (o.flip_index >= 0)
+  {
+    g_forced_draws.clear();
+    g_forced_draws.push_back((int)o.flip_index);
+    // rand() % width + first must give the bit: feed the bit's offset in the ANY range
+    for (int bit : o.flip_bits)
+      g_forced_draws.push_back(bit);
+    g_forced_pos = 0;
+    context->inject_bitflip(A, CGContext::ANY, (int)o.flip_bits.size());
+  }
+  else if (o.num_bit_flips)
+  {
+    srand(o.have_seed ? o.seed : (unsigned)time(NULL));
+    context->inject_bitflip(A, o.bitflip_kind, o.num_bit_flips);
+  }
+
+  auto t0 = std::chrono::steady_clock::now();
+
+  // r = b - A x with x = 0; p = r; rr = r.r
+  context->copy_vector(r, b);
+  context->copy_vector(p, r);
+  double rr = context->dot(r, r);
+
+  int itr = 0;
+  for (; itr < o.max_itrs && rr > o.conv_threshold; itr++)
+  {
+    context->spmv(A, p, w);                                  // w = A p
+    double pw = context->dot(p, w);
+    double alpha = rr / pw;
+    double rr_new = context->calc_xr(x, r, p, w, alpha);     // x += alpha p; r -= alpha w
+    double beta = rr_new / rr;
+    context->calc_p(p, r, beta);                             // p = r + beta p
+    rr = rr_new;
+    if (!o.quiet)
+      printf("iteration %5u :  rr = %12.4lf\n", itr, rr);
+  }
+
+  double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+  printf("\n");
+  printf("ran for %u iterations\n", itr);
+  printf("\ntime taken = %7.2lf ms\n\n", ms);
+
+  // check: r = A x against b
+  context->spmv(A, x, r);
+  double err_sq = 0.0, max_err = 0.0;
+  double *h_r = context->map_vector(r);
+  h_b = context->map_vector(b);
+  for (int i = 0; i < N; i++)
+  {
+    double err = fabs(h_b[i] - h_r[i]);
+    err_sq += err * err;
+    max_err = err > max_err ? err : max_err;
+  }
+  context->unmap_vector(b, h_b);
+  context->unmap_vector(r, h_r);
+  printf("total error = %lf\n", sqrt(err_sq));
+  printf("max error   = %lf\n", max_err);
+  printf("\n");
+
+  context->destroy_matrix(A);
+  context->destroy_vector(b);
+  context->destroy_vector(x);
+  context->destroy_vector(r);
+  context->destroy_vector(p);
+  context->destroy_vector(w);
+  delete context;
+  return 0;
+}

@@ -1,0 +1,111 @@
+"""The cg-csr / cg-coo executables (C++ host side: CGContext registry, HIPContext,
+driver, Matrix-Market loader) against the REFERENCE driver's own transcripts on
+the same input (tests/golden/cli.json: reference cg-csr / cg-coo, -t cpu, on
+tests/golden/lap64.mtx).  Everything the reference prints is compared: the
+report block, every iteration's rr (to the 4 printed decimals, allowing the last
+digit to differ by one: the GPU dot products are tree sums), the iteration
+count, and the error lines."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "abft_sparse_cg_amd", "host")
+G = os.path.join(ROOT, "tests", "golden")
+MTX = os.path.join(G, "lap64.mtx")
+
+
+def exe(fmt):
+    p = os.path.join(HOST, "cg-" + fmt)
+    if not os.path.exists(p):
+        subprocess.check_call(["make", "-C", HOST])
+    return p
+
+
+def run(fmt, args):
+    return subprocess.run([exe(fmt)] + args, capture_output=True, text=True, timeout=300)
+
+
+def numbers_close(a, b, tol):
+    return abs(float(a) - float(b)) <= tol
+
+
+def compare_transcripts(ours, ref):
+    ours = re.sub(r"time taken = .*", "time taken = <T> ms", ours).replace("= hip-", "= cpu-")
+    lo, lr = ours.split("\n"), ref.split("\n")
+    assert len(lo) == len(lr)
+    for a, b in zip(lo, lr):
+        if a == b:
+            continue
+        ma, mb = re.match(r"(iteration +\d+ :  rr = +)([0-9.]+)$", a), re.match(r"(iteration +\d+ :  rr = +)([0-9.]+)$", b)
+        assert ma and mb and ma.group(1).split() == mb.group(1).split(), (a, b)
+        assert numbers_close(ma.group(2), mb.group(2), 1.01e-4 + 1e-10 * float(mb.group(2))), (a, b)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_cli_transcripts_match_reference(fmt):
+    runs = [r for r in json.load(open(os.path.join(G, "cli.json"))) if r["fmt"] == fmt]
+    assert len(runs) == 13
+    for r in runs:
+        if r["args"] == ["--list"]:
+            out = run(fmt, ["--list"])
+            assert out.returncode == 0
+            assert out.stdout == r["stdout"].replace("cpu-", "hip-").replace("\thip-secded\n", "\thip-secded\n\thip-sec\n")
+            continue
+        out = run(fmt, ["-f", MTX, "-t", "hip"] + r["args"])
+        assert out.returncode == r["exit"] == 0, out.stdout[-500:] + out.stderr
+        compare_transcripts(out.stdout, r["stdout"])
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_run_tests_script_passes(fmt):
+    p = subprocess.run([os.path.join(HOST, "run_tests"), exe(fmt)], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout
+    assert "FAILED" not in p.stdout and p.stdout.count("passed") >= 7 + 1 + 4 * 3 + 1
+
+
+@pytest.mark.parametrize("fmt,bit,msg", [("csr", 70, "[ECC] corrected bit 70 at index 1234\n"),
+                                         ("coo", 70, "[ECC] corrected bit 70 at index 1234\n")])
+def test_replayed_flip_is_corrected_once(fmt, bit, msg):
+    """-x replay: the correction line appears exactly once (the write-back
+    persists) and the solve then equals the fault-free one."""
+    clean = run(fmt, ["-f", MTX, "-b", "1", "-m", "secded"])
+    hit = run(fmt, ["-f", MTX, "-b", "1", "-m", "secded", "--flip-at", "1234:%d" % bit])
+    assert clean.returncode == 0 and hit.returncode == 0
+    assert hit.stdout.count(msg) == 1 and hit.stdout.count("[ECC]") == 1
+    assert "*** flipping bit %d at index 1234 ***\n" % bit in hit.stdout
+    strip = lambda s: re.sub(r"time taken = .*", "", s.replace(msg, "").replace("*** flipping bit %d at index 1234 ***\n" % bit, ""))
+    assert strip(hit.stdout) == strip(clean.stdout)
+
+
+def test_sed_detects_and_exits_1():
+    out = run("csr", ["-f", MTX, "-b", "1", "-m", "sed", "--flip-at", "77:3"])
+    assert out.returncode == 1
+    assert out.stdout.endswith("[ECC] error detected at index 77\n")
+    out = run("csr", ["-f", MTX, "-b", "1", "-m", "secded", "--flip-at", "77:3,64"])
+    assert out.returncode == 1 and out.stdout.endswith("[ECC] double-bit error detected\n")
+
+
+def test_cli_errors_like_reference():
+    assert run("csr", ["-t", "cpu"]).returncode == 1  # not registered in this executable
+    out = run("csr", ["-f", "/nonexistent.mtx"])
+    assert out.returncode == 1 and out.stdout == "Failed to open '/nonexistent.mtx'\n"
+    out = run("csr", ["--bogus"])
+    assert out.returncode == 1 and out.stdout == "Unrecognized argument '--bogus' (try '--help')\n"
+    out = run("csr", ["-i", "x"])
+    assert out.returncode == 1 and out.stdout == "Invalid number of iterations\n"
+    assert run("csr", ["--help"]).returncode == 0
+
+
+def test_synthetic_input_and_fixed_iterations():
+    out = run("csr", ["-s", "laplace5:300,300", "-i", "50", "-c", "0", "-q", "-m", "sec8"])
+    assert out.returncode == 0
+    assert "matrix size           = 90000 x 90000\n" in out.stdout
+    assert "number of non-zeros   = 448800 " in out.stdout
+    assert "ran for 50 iterations\n" in out.stdout
+    assert "iteration " not in out.stdout
