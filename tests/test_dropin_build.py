@@ -1,0 +1,42 @@
+"""The drop-in claim of INTEGRATION.md, checked where the reference tree exists:
+the five host-side files compile (as C++11) against the REFERENCE's own
+CGContext.h and link into the reference's cg-csr / cg-coo next to its CPU
+backends, without touching cg.cpp or CGContext.*; --list then shows both targets.
+Build products go to a temporary directory; nothing of the reference is copied
+into the repository."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+PKG = os.path.join(ROOT, "abft_sparse_cg_amd")
+
+pytestmark = [pytest.mark.ref,
+              pytest.mark.skipif(not os.path.exists(os.path.join(REF, "cg.cpp")), reason="no reference tree"),
+              pytest.mark.skipif(not os.path.exists(os.path.join(PKG, "libabft_hip.so")), reason="library not built")]
+
+
+@pytest.mark.parametrize("fmt", ["CSR", "COO"])
+def test_hipcontext_links_into_reference_driver(tmp_path, fmt):
+    d = str(tmp_path)
+    os.makedirs(os.path.join(d, fmt))
+    shutil.copy(os.path.join(ROOT, "include", "abft_hip.h"), d)
+    for f in ("HIPContext.h", "HIPContext.cpp"):
+        shutil.copy(os.path.join(PKG, "host", f), d)
+    shutil.copy(os.path.join(PKG, "host", fmt, "HIPContext.cpp"), os.path.join(d, fmt))
+    cxx = ["g++", "-std=gnu++11", "-I", d, "-I", REF, "-O1", "-Wall", "-Werror", "-fopenmp"]
+    subprocess.check_call(cxx + ["-c", os.path.join(d, "HIPContext.cpp"), "-o", os.path.join(d, "HIPContext.o")])
+    subprocess.check_call(cxx + ["-c", os.path.join(d, fmt, "HIPContext.cpp"), "-o", os.path.join(d, fmt, "reg.o")])
+    exe = os.path.join(d, "cg")
+    subprocess.check_call(["g++", "-std=gnu++11", "-I", REF, "-O1", "-fno-strict-aliasing", "-fopenmp", "-w",
+                           os.path.join(REF, "cg.cpp"), os.path.join(REF, "CGContext.cpp"),
+                           os.path.join(REF, fmt, "CPUContext.cpp"), os.path.join(d, "HIPContext.o"),
+                           os.path.join(d, fmt, "reg.o"), "-x", "c", os.path.join(REF, "mmio.c"), "-x", "none",
+                           "-L" + PKG, "-labft_hip", "-Wl,-rpath," + PKG, "-o", exe])
+    out = subprocess.run([exe, "--list"], capture_output=True, text=True).stdout
+    pairs = [l.strip() for l in out.splitlines() if "-" in l]
+    assert pairs == ["cpu-none", "cpu-constraints", "cpu-sed", "cpu-sec7", "cpu-sec8", "cpu-secded",
+                     "hip-none", "hip-constraints", "hip-sed", "hip-sec7", "hip-sec8", "hip-secded", "hip-sec"]
