@@ -224,8 +224,9 @@ class HIPContext:
             raise FatalEvent(events)
 
     # ---- measurement ------------------------------------------------------
-    def profile(self, on=True):
-        check(self.L.abft_hip_profile_enable(self.h, int(on)))
+    def profile(self, mask=0xF):
+        """bit k of mask brackets kernel k (capi.K_*) with HIP events; 0 = off"""
+        check(self.L.abft_hip_profile_enable(self.h, 0xF if mask is True else int(mask)))
         check(self.L.abft_hip_profile_reset(self.h))
 
     def profile_read(self, kernel):

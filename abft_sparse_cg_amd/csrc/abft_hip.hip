@@ -37,12 +37,6 @@ extern "C" const char *abft_hip_last_error(void) { return g_err; }
 
 // ----------------------------------------------------------------- handles --
 
-struct HostSlot {
-  double value;
-  uint32_t evcount;
-  uint32_t pad;
-};
-
 struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
   double total_ms = 0.0;
@@ -53,11 +47,23 @@ struct abft_hip_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   double *partials = nullptr;  // ABFT_MAX_PARTIALS doubles
+  uint32_t *ticket = nullptr;  // reduction arrival counter (device)
+  uint32_t seq = 0;            // last sequence number handed to a reduction
+  bool spin_wait = true;       // wait for scalars by polling the pinned slot
   HostSlot *host_slot = nullptr;      // pinned, device-visible
   HostSlot *host_slot_dev = nullptr;  // its device alias
   EventRing ring{};                   // device memory
   int *bits_dev = nullptr;            // scratch for inject (32 ints)
-  bool prof = false;
+  // cross-call fusion: the last spmv also produced vec.result (see FuseOut)
+  bool fuse_enabled = true;
+  struct {
+    bool valid = false, have_value = false;
+    const double *x = nullptr, *y = nullptr;
+    int n = 0;
+    uint32_t seq = 0;
+    double value = 0.0;
+  } fused;
+  unsigned prof = 0;  // bit k: bracket launches of kernel k with HIP events
   ProfSlot prof_k[ABFT_K_COUNT];
   std::vector<hipEvent_t> ev_pool;
 };
@@ -67,6 +73,7 @@ struct abft_hip_matrix {
   int fmt = 0, mode = 0;
   CsrDev csr{};
   CooDev coo{};
+  double *fuse_partials = nullptr;  // FuseOut buffer (square matrices)
   std::vector<void *> allocs;
 };
 
@@ -93,13 +100,13 @@ struct KernelTimer {
   int id;
   hipEvent_t a = nullptr, b = nullptr;
   KernelTimer(abft_hip_ctx *c, int k) : ctx(c), id(k) {
-    if (!ctx->prof) return;
+    if (!(ctx->prof >> id & 1u)) return;
     a = take();
     b = take();
     if (a && b) (void)hipEventRecord(a, ctx->stream);
   }
   ~KernelTimer() {
-    if (!ctx->prof || !a || !b) return;
+    if (!a || !b) return;
     (void)hipEventRecord(b, ctx->stream);
     ctx->prof_k[id].pending.emplace_back(a, b);
     if (ctx->prof_k[id].pending.size() >= 4096) fold(ctx, id);
@@ -163,7 +170,11 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
   HIPCHK(hipMalloc((void **)&ctx->partials, ABFT_MAX_PARTIALS * sizeof(double)));
-  HIPCHK(hipHostMalloc((void **)&ctx->host_slot, sizeof(HostSlot), hipHostMallocMapped));
+  HIPCHK(hipMalloc((void **)&ctx->ticket, ABFT_TICKET_WORDS * sizeof(uint32_t)));
+  HIPCHK(hipMemset(ctx->ticket, 0, ABFT_TICKET_WORDS * sizeof(uint32_t)));
+  if (const char *e = getenv("ABFT_HIP_SYNC")) ctx->spin_wait = strcmp(e, "stream") != 0;
+  if (const char *e = getenv("ABFT_HIP_FUSE_DOT")) ctx->fuse_enabled = strcmp(e, "0") != 0;
+  HIPCHK(hipHostMalloc((void **)&ctx->host_slot, sizeof(HostSlot), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->host_slot, 0, sizeof(HostSlot));
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->host_slot_dev, ctx->host_slot, 0));
   HIPCHK(hipMalloc((void **)&ctx->ring.buf, EVENT_CAP * sizeof(abft_event)));
@@ -182,6 +193,7 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   for (int k = 0; k < ABFT_K_COUNT; k++) KernelTimer::fold(ctx, k);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->ticket);
   (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
   (void)hipFree(ctx->ring.count);
@@ -233,17 +245,16 @@ static void matrix_free(abft_hip_matrix *m) {
 // `align2`: the tile starts at the even element at or below the block's first
 // element (CSR pair loads), so that one counts against the capacity too.
 static void cut_blocks(const uint32_t *ptr, uint32_t n, uint32_t tile, bool align2,
-                       std::vector<uint32_t> &blk) {
+                       std::vector<uint4> &blk) {
   const uint32_t max_segments = 4 * ABFT_BLOCK;
   blk.clear();
-  blk.push_back(0);
   uint32_t s = 0;
   while (s < n) {
     const uint32_t base = align2 ? (ptr[s] & ~1u) : ptr[s];
     uint32_t e = s;
     while (e < n && e - s < max_segments && ptr[e + 1] >= ptr[e] && ptr[e + 1] - base <= tile) e++;
     if (e == s) e = s + 1;  // a single segment longer than a tile: walked tile by tile
-    blk.push_back(e);
+    blk.push_back(make_uint4(s, e, ptr[s], ptr[e]));
     s = e;
   }
 }
@@ -271,15 +282,16 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   for (int i = 0; i < nnz; i++)
     while (next <= rows[i]) rowptr[next++] = (uint32_t)i;
   while (next <= (uint32_t)n_out) rowptr[next++] = (uint32_t)nnz;
-  std::vector<uint32_t> blk;
+  std::vector<uint4> blk;
   cut_blocks(rowptr.data(), (uint32_t)n_out, ABFT_CSR_TILE, true, blk);
 
   CsrDev &A = m->csr;
   A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
-  A.nblk = (uint32_t)blk.size() - 1;
+  A.nblk = (uint32_t)blk.size();
   const size_t padded = ((size_t)nnz + 3) & ~(size_t)1;  // even, >= nnz + 2
   int rc;
-  uint32_t *d_rowptr = nullptr, *d_blk = nullptr;
+  uint32_t *d_rowptr = nullptr;
+  uint4 *d_blk = nullptr;
   if ((rc = dev_upload(m, &A.cols, columns, (size_t)nnz, padded)) ||
       (rc = dev_upload(m, &A.vals, values, (size_t)nnz, padded)) ||
       (rc = dev_upload(m, &d_rowptr, rowptr.data(), rowptr.size(), rowptr.size())) ||
@@ -288,7 +300,7 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     return rc;
   }
   A.rowptr = d_rowptr;
-  A.blk_row = d_blk;
+  A.blk = d_blk;
   hipError_t e = launch_encode_csr(mode, A.cols, A.vals, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host arrays may be freed on return
   if (e != hipSuccess) {
@@ -327,15 +339,15 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     orig[p] = (uint32_t)i;
     pos[i] = p;
   }
-  std::vector<uint32_t> blk;
+  std::vector<uint4> blk;
   cut_blocks(grp.data(), (uint32_t)n_out, ABFT_COO_TILE, false, blk);
 
   CooDev &A = m->coo;
   A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
-  A.nblk = (uint32_t)blk.size() - 1;
+  A.nblk = (uint32_t)blk.size();
   int rc;
-  uint32_t *d_grp = nullptr, *d_blk = nullptr, *d_orig = nullptr, *d_pos = nullptr;
-  uint4 *d_el = nullptr;
+  uint32_t *d_grp = nullptr, *d_orig = nullptr, *d_pos = nullptr;
+  uint4 *d_el = nullptr, *d_blk = nullptr;
   if ((rc = dev_upload(m, &d_el, reinterpret_cast<const uint4 *>(elems.data()), (size_t)nnz, (size_t)nnz + 1)) ||
       (rc = dev_upload(m, &d_grp, grp.data(), grp.size(), grp.size())) ||
       (rc = dev_upload(m, &d_blk, blk.data(), blk.size(), blk.size())) ||
@@ -344,7 +356,7 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     matrix_free(m);
     return rc;
   }
-  A.elems = d_el; A.grp_ptr = d_grp; A.blk_grp = d_blk; A.orig_index = d_orig; A.pos_of_orig = d_pos;
+  A.elems = d_el; A.grp_ptr = d_grp; A.blk = d_blk; A.orig_index = d_orig; A.pos_of_orig = d_pos;
   hipError_t e = launch_encode_coo(mode, A.elems, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
@@ -364,9 +376,22 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
   if (mode < ABFT_MODE_NONE || mode > ABFT_MODE_SECDED) return set_err(ABFT_ERR_INVALID, "unknown mode %d", mode);
   if (n_out < 0 || n_in < 0 || nnz < 0) return set_err(ABFT_ERR_INVALID, "negative size");
   if (nnz && (!columns || !rows || !values)) return set_err(ABFT_ERR_INVALID, "null input array");
-  if (format == ABFT_FMT_CSR) return create_csr(ctx, mode, columns, rows, values, n_out, n_in, nnz, index_base, out);
-  if (format == ABFT_FMT_COO) return create_coo(ctx, mode, columns, rows, values, n_out, n_in, nnz, index_base, out);
-  return set_err(ABFT_ERR_INVALID, "unknown format %d", format);
+  int rc;
+  if (format == ABFT_FMT_CSR) rc = create_csr(ctx, mode, columns, rows, values, n_out, n_in, nnz, index_base, out);
+  else if (format == ABFT_FMT_COO) rc = create_coo(ctx, mode, columns, rows, values, n_out, n_in, nnz, index_base, out);
+  else return set_err(ABFT_ERR_INVALID, "unknown format %d", format);
+  if (rc != ABFT_OK) return rc;
+  abft_hip_matrix *m = *out;
+  const uint32_t nblk = format == ABFT_FMT_CSR ? m->csr.nblk : m->coo.nblk;
+  if (n_out == n_in && nblk > 0) {  // square: spmv can also deliver vec.result
+    if (hipMalloc((void **)&m->fuse_partials, (size_t)nblk * sizeof(double)) != hipSuccess) {
+      matrix_free(m);
+      *out = nullptr;
+      return set_err(ABFT_ERR_NOMEM, "fusion buffer for %u blocks does not fit", nblk);
+    }
+    m->allocs.push_back(m->fuse_partials);
+  }
+  return ABFT_OK;
 }
 
 extern "C" int abft_hip_matrix_create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns,
@@ -475,6 +500,7 @@ extern "C" int abft_hip_vector_view(abft_hip_vector *parent, int offset, int N, 
 extern "C" int abft_hip_vector_destroy(abft_hip_vector *vec) {
   if (!vec) return ABFT_OK;
   if (int rc = bind(vec->ctx)) return rc;
+  vec->ctx->fused.valid = false;
   HIPCHK(hipStreamSynchronize(vec->ctx->stream));
   if (vec->host) (void)hipHostFree(vec->host);
   if (vec->owns) (void)hipFree(vec->d);
@@ -495,6 +521,7 @@ extern "C" int abft_hip_vector_map(abft_hip_vector *vec, double **host) {
 extern "C" int abft_hip_vector_unmap(abft_hip_vector *vec, double *host) {
   if (!vec || !host) return set_err(ABFT_ERR_INVALID, "null argument");
   if (int rc = bind(vec->ctx)) return rc;
+  vec->ctx->fused.valid = false;
   if (vec->n) HIPCHK(hipMemcpyAsync(vec->d, host, (size_t)vec->n * sizeof(double), hipMemcpyHostToDevice, vec->ctx->stream));
   if (host != vec->host) HIPCHK(hipStreamSynchronize(vec->ctx->stream));  // caller's buffer: done with it on return
   return ABFT_OK;
@@ -504,6 +531,7 @@ extern "C" int abft_hip_vector_copy(abft_hip_vector *dst, const abft_hip_vector 
   if (!dst || !src) return set_err(ABFT_ERR_INVALID, "null vector");
   if (src->n < dst->n) return set_err(ABFT_ERR_INVALID, "copy of %d elements from a vector of %d", dst->n, src->n);
   if (int rc = bind(dst->ctx)) return rc;
+  dst->ctx->fused.valid = false;
   if (dst->n) HIPCHK(hipMemcpyAsync(dst->d, src->d, (size_t)dst->n * sizeof(double), hipMemcpyDeviceToDevice, dst->ctx->stream));
   return ABFT_OK;
 }
@@ -513,11 +541,43 @@ extern "C" int abft_hip_vector_length(abft_hip_vector *vec) { return vec ? vec->
 
 // --------------------------------------------------------------- CG kernels --
 
-static int scalar_to_host(abft_hip_ctx *ctx, int nparts, double *result) {
-  HIPCHK(launch_finalize(ctx->partials, nparts, nullptr, &ctx->host_slot_dev->value, ctx->ring.count,
-                         &ctx->host_slot_dev->evcount, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  *result = ctx->host_slot->value;
+static ReduceOut reduce_out(abft_hip_ctx *ctx, double *dev_out, bool to_host) {
+  ReduceOut o;
+  o.partials = ctx->partials;
+  o.ticket = ctx->ticket;
+  o.dev_out = dev_out;
+  o.host = to_host ? ctx->host_slot_dev : nullptr;
+  o.ev_count = ctx->ring.count;
+  o.seq = to_host ? ++ctx->seq : 0;
+  return o;
+}
+
+// Wait for the reduction that was given sequence number `seq` to publish its
+// result in the pinned slot.  Polling the slot costs a couple of microseconds
+// once the value lands; hipStreamSynchronize costs tens.  The stream is queried
+// now and then so that a failed kernel ends the wait with an error instead of a hang.
+static int scalar_from_host_slot(abft_hip_ctx *ctx, uint32_t seq, double *result) {
+  HostSlot *slot = ctx->host_slot;
+  if (!ctx->spin_wait) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  } else {
+    for (;;) {
+      bool ready = false;
+      for (int i = 0; i < 4096 && !ready; i++) {
+        ready = __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) == seq;
+        if (!ready) __builtin_ia32_pause();
+      }
+      if (ready) break;
+      const hipError_t q = hipStreamQuery(ctx->stream);
+      if (q == hipSuccess) break;  // the stream drained: the slot is final either way
+      if (q != hipErrorNotReady)
+        return set_err(ABFT_ERR_HIP, "stream failed while waiting for a reduction: %s", hipGetErrorString(q));
+    }
+  }
+  if (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != seq)
+    return set_err(ABFT_ERR_HIP, "reduction %u finished without publishing its result (slot holds %u)", seq,
+                   slot->seq);
+  *result = slot->value;
   return ABFT_OK;
 }
 
@@ -531,33 +591,42 @@ extern "C" int abft_hip_dot(abft_hip_ctx *ctx, const abft_hip_vector *a, const a
   if (int rc = bind(ctx)) return rc;
   if (int rc = check_same(a, b, "dot")) return rc;
   if (!result) return set_err(ABFT_ERR_INVALID, "null result");
+  // dot(p, w) right after spmv(A, p, w): the SpMV already formed it
+  if (ctx->fused.valid && a->n == ctx->fused.n &&
+      ((a->d == ctx->fused.x && b->d == ctx->fused.y) || (a->d == ctx->fused.y && b->d == ctx->fused.x))) {
+    if (!ctx->fused.have_value) {
+      if (int rc = scalar_from_host_slot(ctx, ctx->fused.seq, &ctx->fused.value)) return rc;
+      ctx->fused.have_value = true;
+    }
+    *result = ctx->fused.value;
+    return ABFT_OK;
+  }
+  if (!ctx->fused.have_value) ctx->fused.valid = false;  // the slot is about to be reused
+  const ReduceOut o = reduce_out(ctx, nullptr, true);
   {
     KernelTimer t(ctx, ABFT_K_DOT);
-    HIPCHK(launch_dot(a->d, b->d, a->n, ctx->partials, ctx->stream));
+    HIPCHK(launch_dot(a->d, b->d, a->n, o, ctx->stream));
   }
-  return scalar_to_host(ctx, reduce_blocks(a->n), result);
+  return scalar_from_host_slot(ctx, o.seq, result);
 }
 
 extern "C" int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b, double *dev_result) {
   if (int rc = bind(ctx)) return rc;
   if (int rc = check_same(a, b, "dot")) return rc;
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
-  {
-    KernelTimer t(ctx, ABFT_K_DOT);
-    HIPCHK(launch_dot(a->d, b->d, a->n, ctx->partials, ctx->stream));
-  }
-  HIPCHK(launch_finalize(ctx->partials, reduce_blocks(a->n), dev_result, nullptr, ctx->ring.count,
-                         &ctx->host_slot_dev->evcount, ctx->stream));
+  KernelTimer t(ctx, ABFT_K_DOT);
+  HIPCHK(launch_dot(a->d, b->d, a->n, reduce_out(ctx, dev_result, false), ctx->stream));
   return ABFT_OK;
 }
 
 static int calc_xr_launch(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r, const abft_hip_vector *p,
-                          const abft_hip_vector *w, double alpha) {
+                          const abft_hip_vector *w, double alpha, const ReduceOut &o) {
   if (int rc = check_same(x, r, "calc_xr")) return rc;
   if (int rc = check_same(x, p, "calc_xr")) return rc;
   if (int rc = check_same(x, w, "calc_xr")) return rc;
+  ctx->fused.valid = false;
   KernelTimer t(ctx, ABFT_K_CALC_XR);
-  HIPCHK(launch_calc_xr(x->d, r->d, p->d, w->d, alpha, x->n, ctx->partials, ctx->stream));
+  HIPCHK(launch_calc_xr(x->d, r->d, p->d, w->d, alpha, x->n, o, ctx->stream));
   return ABFT_OK;
 }
 
@@ -565,8 +634,9 @@ extern "C" int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_
                                 const abft_hip_vector *w, double alpha, double *result) {
   if (int rc = bind(ctx)) return rc;
   if (!result) return set_err(ABFT_ERR_INVALID, "null result");
-  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha)) return rc;
-  return scalar_to_host(ctx, reduce_blocks(x->n), result);
+  const ReduceOut o = reduce_out(ctx, nullptr, true);
+  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha, o)) return rc;
+  return scalar_from_host_slot(ctx, o.seq, result);
 }
 
 extern "C" int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
@@ -574,15 +644,13 @@ extern "C" int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_
                                     double *dev_result) {
   if (int rc = bind(ctx)) return rc;
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
-  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha)) return rc;
-  HIPCHK(launch_finalize(ctx->partials, reduce_blocks(x->n), dev_result, nullptr, ctx->ring.count,
-                         &ctx->host_slot_dev->evcount, ctx->stream));
-  return ABFT_OK;
+  return calc_xr_launch(ctx, x, r, p, w, alpha, reduce_out(ctx, dev_result, false));
 }
 
 extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r, double beta) {
   if (int rc = bind(ctx)) return rc;
   if (int rc = check_same(p, r, "calc_p")) return rc;
+  ctx->fused.valid = false;
   KernelTimer t(ctx, ABFT_K_CALC_P);
   HIPCHK(launch_calc_p(p->d, r->d, beta, p->n, ctx->stream));
   return ABFT_OK;
@@ -599,11 +667,35 @@ extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft
     return set_err(ABFT_ERR_INVALID, "spmv: vectors (%d in, %d out) shorter than the matrix (%u in, %u out)",
                    vec->n, result->n, n_in, n_out);
   if (vec->d == result->d) return set_err(ABFT_ERR_INVALID, "spmv: input and output alias");
-  KernelTimer t(ctx, ABFT_K_SPMV);
-  if (mat->fmt == ABFT_FMT_CSR)
-    HIPCHK(launch_spmv_csr(mat->mode, mat->csr, vec->d, result->d, ctx->ring, ctx->stream));
-  else
-    HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, ctx->stream));
+  ctx->fused.valid = false;
+  FuseOut fuse{};
+  const bool do_fuse = ctx->fuse_enabled && mat->fuse_partials && n_in == n_out &&
+                       (uint32_t)vec->n == n_in && (uint32_t)result->n == n_out;
+  if (do_fuse) {
+    fuse.partials = mat->fuse_partials;
+    fuse.host = ctx->host_slot_dev;
+    fuse.ev_count = ctx->ring.count;
+    fuse.seq = ++ctx->seq;
+  }
+  {
+    KernelTimer t(ctx, ABFT_K_SPMV);
+    if (mat->fmt == ABFT_FMT_CSR)
+      HIPCHK(launch_spmv_csr(mat->mode, mat->csr, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
+    else
+      HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
+  }
+  if (do_fuse) {
+    KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
+    HIPCHK(launch_fuse_finalize(fuse, mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk, ctx->stream));
+  }
+  if (do_fuse) {
+    ctx->fused.valid = true;
+    ctx->fused.have_value = false;
+    ctx->fused.x = vec->d;
+    ctx->fused.y = result->d;
+    ctx->fused.n = vec->n;
+    ctx->fused.seq = fuse.seq;
+  }
   return ABFT_OK;
 }
 
@@ -671,7 +763,7 @@ extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap
 
 extern "C" int abft_hip_profile_enable(abft_hip_ctx *ctx, int on) {
   if (int rc = bind(ctx)) return rc;
-  ctx->prof = on != 0;
+  ctx->prof = on < 0 ? 0u : (unsigned)on & ((1u << ABFT_K_COUNT) - 1u);
   return ABFT_OK;
 }
 

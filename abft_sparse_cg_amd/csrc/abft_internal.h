@@ -20,7 +20,7 @@ struct CsrDev {
   uint32_t *cols;
   double *vals;
   const uint32_t *rowptr;   // n_out + 1
-  const uint32_t *blk_row;  // nblk + 1 : first row of each row block
+  const uint4 *blk;         // nblk : {first row, end row, first element, end element} of each row block
   uint32_t nblk, n_out, n_in, nnz, index_base;
 };
 
@@ -30,7 +30,7 @@ struct CsrDev {
 struct CooDev {
   uint4 *elems;
   const uint32_t *grp_ptr;      // n_out + 1
-  const uint32_t *blk_grp;      // nblk + 1
+  const uint4 *blk;             // nblk : {first group, end group, first element, end element}
   const uint32_t *orig_index;   // stored position -> caller's element index (cold path)
   const uint32_t *pos_of_orig;  // caller's element index -> stored position
   uint32_t nblk, n_out, n_in, nnz, index_base;
@@ -49,7 +49,10 @@ struct CooDev {
 #define ABFT_CFG_NT 1  // stream cols/vals with the non-temporal hint
 #endif
 #ifndef ABFT_CFG_XCD
-#define ABFT_CFG_XCD 1  // XCD-aware tile order
+#define ABFT_CFG_XCD 1  // tile order: 0 dispatch order, 1 contiguous range per XCD, 2 chunked
+#endif
+#ifndef ABFT_CFG_XCD_CHUNK
+#define ABFT_CFG_XCD_CHUNK 32
 #endif
 
 constexpr int ABFT_BLOCK = 256;
@@ -58,28 +61,61 @@ constexpr int ABFT_CSR_TILE = ABFT_BLOCK * ABFT_CSR_EPT;  // nnz staged per bloc
 constexpr int ABFT_COO_EPT = ABFT_CFG_COO_EPT;
 constexpr int ABFT_COO_TILE = ABFT_BLOCK * ABFT_COO_EPT;
 constexpr int ABFT_MAX_PARTIALS = 2048;  // reduction blocks (256 CUs x 8)
+constexpr int ABFT_TICKET_GROUP = 32;    // blocks per first-level arrival counter
+constexpr int ABFT_TICKET_WORDS = 1 + ABFT_MAX_PARTIALS / ABFT_TICKET_GROUP;  // [0] top, [1..] groups
 
 hipError_t launch_encode_csr(int mode, uint32_t *cols, double *vals, uint32_t nnz, hipStream_t s);
 hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s);
-hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,
-                           hipStream_t s);
-hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
-                           hipStream_t s);
 hipError_t launch_inject_csr(double *vals, uint32_t *cols, uint32_t index, const int *bits_dev,
                              int nbits, hipStream_t s);
 hipError_t launch_inject_coo(uint4 *elems, const uint32_t *pos_of_orig, uint32_t index,
                              const int *bits_dev, int nbits, hipStream_t s);
 
-// Reductions: stage 1 writes one partial per block into `partials`
-// (ABFT_MAX_PARTIALS doubles), stage 2 sums them in a fixed order and writes
-// the scalar to dev_out and/or host_out (pinned, device-visible), together
-// with the event count when ev_count/host_evcount are given.
+// Pinned, device-visible result slot: the reduction's last block writes the
+// scalar and the queued-event count, then publishes `seq` with a system-scope
+// release store; the host spins on `seq` instead of synchronising the stream.
+struct HostSlot {
+  double value;
+  uint32_t evcount;
+  uint32_t seq;
+};
+
+// Where a reduction delivers its result.  Every block writes one partial, takes
+// a ticket (agent-scope release before, acquire after for the last arriver), and
+// the block that draws the last ticket adds the partials in a fixed order, so the
+// value does not depend on which block that is.
+struct ReduceOut {
+  double *partials;          // ABFT_MAX_PARTIALS doubles
+  uint32_t *ticket;          // ABFT_TICKET_WORDS counters, zero between launches (last arrivers reset them)
+  double *dev_out;           // optional: {sum, queued events} as two doubles
+  HostSlot *host;            // optional: device alias of the pinned slot
+  const uint32_t *ev_count;  // the context's device event counter
+  uint32_t seq;              // value to publish in host->seq
+};
+
+// Cross-call fusion: an SpMV on a square matrix also forms
+// sum_row vec[row] * result[row], so the dot(p, w) the CG loop asks for right
+// after spmv(A, p, w) needs no pass over the vectors.  Each block leaves one
+// partial; a one-block kernel behind the SpMV folds them in a fixed order and
+// publishes the scalar like a reduction does.  `partials` belongs to the matrix.
+struct FuseOut {
+  double *partials;  // nblk
+  HostSlot *host;
+  const uint32_t *ev_count;
+  uint32_t seq;
+};
+
+// fuse == nullptr: plain SpMV; otherwise follow with launch_fuse_finalize
+hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s);
+hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,
+                           const FuseOut *fuse, hipStream_t s);
+hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
+                           const FuseOut *fuse, hipStream_t s);
+
 int reduce_blocks(int n);
-hipError_t launch_dot(const double *a, const double *b, int n, double *partials, hipStream_t s);
+hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);
 hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w, double alpha,
-                          int n, double *partials, hipStream_t s);
-hipError_t launch_finalize(const double *partials, int nparts, double *dev_out, double *host_out,
-                           const uint32_t *ev_count, uint32_t *host_evcount, hipStream_t s);
+                          int n, const ReduceOut &out, hipStream_t s);
 hipError_t launch_calc_p(double *p, const double *r, double beta, int n, hipStream_t s);
 hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s);
 hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s);

@@ -30,8 +30,17 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // range of tiles so the x-window its blocks gather from stays in that XCD's L2
 // (speed only; the map is a bijection for every nblk).
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nblk) {
-#if !ABFT_CFG_XCD
+#if ABFT_CFG_XCD == 0
   return b;
+#elif ABFT_CFG_XCD == 2
+  // chunked variant: the 8 XCDs share a window of 8*C consecutive tiles, each
+  // taking C consecutive ones (keeps one HBM stream, still gives an XCD runs of
+  // neighbouring tiles); the ragged tail keeps the identity map
+  constexpr uint32_t C = ABFT_CFG_XCD_CHUNK;
+  const uint32_t full = (nblk / (8u * C)) * (8u * C);
+  if (b >= full) return b;
+  const uint32_t g = b >> 3;
+  return (g / C) * (8u * C) + (b & 7u) * C + g % C;
 #endif
   const uint32_t xcd = b & 7u, q = nblk >> 3, r = nblk & 7u;
   const uint32_t first = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
@@ -108,7 +117,7 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-// fixed-shape block reduction (256 threads = 4 waves); result valid in thread 0
+// fixed-shape block reduction (256 threads = 4 waves); every thread gets the sum
 __device__ __forceinline__ double block_sum(double v, double *s_w) {
   v = wave_sum(v);
   if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = v;
@@ -152,6 +161,51 @@ hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s
   uint32_t grid = (nnz + ABFT_BLOCK - 1) / ABFT_BLOCK;
   if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(encode_coo_kernel, dim3(grid), dim3(ABFT_BLOCK), 0, s, mode, elems, nnz);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------ fused dot epilogue --
+
+// Tail of an SpMV launched with a FuseOut: `dsum` is this thread's share of
+// sum vec[row]*result[row].  The block leaves one partial with a plain store
+// and exits -- nothing here waits on memory.  (An in-kernel ticket protocol
+// was measured first: the storing lane's drain + returning atomic kept every
+// block resident ~2x longer and cost 75 us per SpMV.)  fuse_finalize_kernel,
+// launched behind the SpMV on the same stream, folds the partials in a fixed
+// order and publishes the scalar.
+__device__ __forceinline__ void fused_dot_finish(double dsum, const FuseOut &f) {
+  __shared__ double s_w[4];
+  const double bsum = block_sum(dsum, s_w);
+  if (threadIdx.x == 0) f.partials[blockIdx.x] = bsum;
+}
+
+__global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t nblk) {
+  __shared__ double s_w[16];
+  // fixed order; four independent loads in flight per thread
+  double acc = 0.0;
+  for (uint32_t i = threadIdx.x; i < nblk; i += 4096u) {
+    const double a0 = f.partials[i];
+    const double a1 = i + 1024u < nblk ? f.partials[i + 1024u] : 0.0;
+    const double a2 = i + 2048u < nblk ? f.partials[i + 2048u] : 0.0;
+    const double a3 = i + 3072u < nblk ? f.partials[i + 3072u] : 0.0;
+    acc += (a0 + a1) + (a2 + a3);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < 16; k++) tot += s_w[k];
+    const uint32_t nev = *f.ev_count;
+    __hip_atomic_store(&f.host->value, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&f.host->evcount, nev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&f.host->seq, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s) {
+  hipLaunchKernelGGL(fuse_finalize_kernel, dim3(1), dim3(1024), 0, s, f, nblk);
   return hipGetLastError();
 }
 
@@ -278,78 +332,97 @@ __device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev
 // running sum carried by thread 0 (same order, so still bit-exact).
 //   reference: CSR/CPUContext.cpp:115-133 (none), :162-207 (constraints),
 //              :214-245 (sed), :252-289 (sec7), :297-345 (sec8), :353-411 (secded)
-template <int MODE, int EPT>
+template <int MODE, int EPT, bool FUSE>
 __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const double *__restrict__ x,
-                                                              double *__restrict__ y, EventRing ev) {
+                                                              double *__restrict__ y, EventRing ev,
+                                                              FuseOut fuse) {
   constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[MODE == MODE_CONSTRAINTS ? TILE : 2];
   const uint32_t t = xcd_tile(blockIdx.x, A.nblk);
-  const uint32_t row0 = A.blk_row[t], row1 = A.blk_row[t + 1];
-  const uint32_t e0 = A.rowptr[row0], e1 = A.rowptr[row1];
+  const uint4 desc = A.blk[t];  // one scalar load instead of two dependent pairs
+  const uint32_t row0 = desc.x, row1 = desc.y, e0 = desc.z, e1 = desc.w;
   const uint32_t base = e0 & ~1u;
+  double dsum = 0.0;  // FUSE: this thread's share of sum x[row] * y[row]
 
   if (e1 >= e0 && e1 - base <= TILE) {
     // row pointers for phase 2, requested before the tile so their latency overlaps
     const uint32_t r = row0 + threadIdx.x;
     uint32_t rs = 0, re = 0;
-    if (r < row1) { rs = A.rowptr[r]; re = A.rowptr[r + 1]; }
+    double xr = 0.0;
+    if (r < row1) {
+      rs = A.rowptr[r]; re = A.rowptr[r + 1];
+      if (FUSE) xr = x[r];
+    }
     csr_stage<MODE, EPT>(A, x, ev, base, e0, e1, s_prod, s_col);
     __syncthreads();
     for (uint32_t row = r; row < row1; row += ABFT_BLOCK) {
-      if (row != r) { rs = A.rowptr[row]; re = A.rowptr[row + 1]; }
+      if (row != r) {
+        rs = A.rowptr[row]; re = A.rowptr[row + 1];
+        if (FUSE) xr = x[row];
+      }
       if (MODE == MODE_CONSTRAINTS) {  // reference CSR/CPUContext.cpp:173-182
         if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
         if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
       }
       if (rs < e0 || re > e1 || re < rs) continue;  // inconsistent row pointers: never touch LDS out of range
       double acc = 0.0;
-      if (csr_row_sum<MODE>(A, ev, base, rs, re, re, s_prod, s_col, acc)) y[row] = acc;
+      if (csr_row_sum<MODE>(A, ev, base, rs, re, re, s_prod, s_col, acc)) {
+        y[row] = acc;
+        if (FUSE) dsum += xr * acc;
+      }
     }
-    return;
+  } else {
+    // long row (or inconsistent pointers): rows of this block one at a time, tile by tile
+    for (uint32_t row = row0; row < row1; row++) {
+      const uint32_t rs = A.rowptr[row], re = A.rowptr[row + 1];
+      if (MODE == MODE_CONSTRAINTS) {
+        if (re > A.nnz) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
+        if (re < rs) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
+      }
+      if (re > A.nnz || re < rs) continue;
+      double acc = 0.0;
+      bool ok = true;
+      for (uint32_t lo = rs; lo < re;) {
+        const uint32_t b = lo & ~1u;
+        const uint32_t hi = min(re, b + TILE);
+        __syncthreads();
+        csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+        __syncthreads();
+        if (threadIdx.x == 0 && ok) ok = csr_row_sum<MODE>(A, ev, b, lo, hi, re, s_prod, s_col, acc);
+        lo = hi;
+      }
+      if (threadIdx.x == 0 && ok) {
+        y[row] = acc;
+        if (FUSE) dsum += x[row] * acc;
+      }
+    }
   }
-
-  // long row (or inconsistent pointers): rows of this block one at a time, tile by tile
-  for (uint32_t row = row0; row < row1; row++) {
-    const uint32_t rs = A.rowptr[row], re = A.rowptr[row + 1];
-    if (MODE == MODE_CONSTRAINTS) {
-      if (re > A.nnz) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
-      if (re < rs) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
-    }
-    if (re > A.nnz || re < rs) continue;
-    double acc = 0.0;
-    bool ok = true;
-    for (uint32_t lo = rs; lo < re;) {
-      const uint32_t b = lo & ~1u;
-      const uint32_t hi = min(re, b + TILE);
-      __syncthreads();
-      csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
-      __syncthreads();
-      if (threadIdx.x == 0 && ok) ok = csr_row_sum<MODE>(A, ev, b, lo, hi, re, s_prod, s_col, acc);
-      lo = hi;
-    }
-    if (threadIdx.x == 0 && ok) y[row] = acc;
-  }
+  if (FUSE) fused_dot_finish(dsum, fuse);
 }
 
 template <int MODE>
 static hipError_t launch_spmv_csr_mode(const CsrDev &A, const double *x, double *y, EventRing ev,
-                                       hipStream_t s) {
-  hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A, x,
-                     y, ev);
+                                       const FuseOut *fuse, hipStream_t s) {
+  if (fuse) {
+    hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT, true>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, *fuse);
+  } else
+    hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT, false>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, FuseOut{});
   return hipGetLastError();
 }
 
 hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,
-                           hipStream_t s) {
+                           const FuseOut *fuse, hipStream_t s) {
   if (A.nblk == 0) return hipSuccess;
   switch (mode) {
-    case MODE_NONE: return launch_spmv_csr_mode<MODE_NONE>(A, x, y, ev, s);
-    case MODE_CONSTRAINTS: return launch_spmv_csr_mode<MODE_CONSTRAINTS>(A, x, y, ev, s);
-    case MODE_SED: return launch_spmv_csr_mode<MODE_SED>(A, x, y, ev, s);
-    case MODE_SEC7: return launch_spmv_csr_mode<MODE_SEC7>(A, x, y, ev, s);
-    case MODE_SEC8: return launch_spmv_csr_mode<MODE_SEC8>(A, x, y, ev, s);
-    case MODE_SECDED: return launch_spmv_csr_mode<MODE_SECDED>(A, x, y, ev, s);
+    case MODE_NONE: return launch_spmv_csr_mode<MODE_NONE>(A, x, y, ev, fuse, s);
+    case MODE_CONSTRAINTS: return launch_spmv_csr_mode<MODE_CONSTRAINTS>(A, x, y, ev, fuse, s);
+    case MODE_SED: return launch_spmv_csr_mode<MODE_SED>(A, x, y, ev, fuse, s);
+    case MODE_SEC7: return launch_spmv_csr_mode<MODE_SEC7>(A, x, y, ev, fuse, s);
+    case MODE_SEC8: return launch_spmv_csr_mode<MODE_SEC8>(A, x, y, ev, fuse, s);
+    case MODE_SECDED: return launch_spmv_csr_mode<MODE_SECDED>(A, x, y, ev, fuse, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -438,63 +511,81 @@ __device__ __forceinline__ double lds_ordered_sum(const double *s_prod, uint32_t
 // order, so an output's contributions are added in exactly the order the
 // reference's serial loop adds them; the workgroup/tile structure is the CSR
 // one with (group, grp_ptr) in place of (row, rowptr).
-template <int MODE, int EPT>
+template <int MODE, int EPT, bool FUSE>
 __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const double *__restrict__ x,
-                                                              double *__restrict__ y, EventRing ev) {
+                                                              double *__restrict__ y, EventRing ev,
+                                                              FuseOut fuse) {
   constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
   const uint32_t t = xcd_tile(blockIdx.x, A.nblk);
-  const uint32_t g0 = A.blk_grp[t], g1 = A.blk_grp[t + 1];
-  const uint32_t e0 = A.grp_ptr[g0], e1 = A.grp_ptr[g1];
+  const uint4 desc = A.blk[t];
+  const uint32_t g0 = desc.x, g1 = desc.y, e0 = desc.z, e1 = desc.w;
+  double dsum = 0.0;
 
   if (e1 - e0 <= TILE) {
     const uint32_t g = g0 + threadIdx.x;
     uint32_t gs = 0, ge = 0;
-    if (g < g1) { gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1]; }
+    double xg = 0.0;
+    if (g < g1) {
+      gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1];
+      if (FUSE) xg = x[g];
+    }
     coo_stage<MODE, EPT>(A, x, ev, e0, e1, s_prod);
     __syncthreads();
     for (uint32_t grp = g; grp < g1; grp += ABFT_BLOCK) {
-      if (grp != g) { gs = A.grp_ptr[grp]; ge = A.grp_ptr[grp + 1]; }
+      if (grp != g) {
+        gs = A.grp_ptr[grp]; ge = A.grp_ptr[grp + 1];
+        if (FUSE) xg = x[grp];
+      }
       // reference zero-fills result first (COO/CPUContext.cpp:108-109)
-      y[grp] = lds_ordered_sum(s_prod, gs - e0, ge - e0);
+      const double acc = lds_ordered_sum(s_prod, gs - e0, ge - e0);
+      y[grp] = acc;
+      if (FUSE) dsum += xg * acc;
     }
-    return;
-  }
-
-  for (uint32_t grp = g0; grp < g1; grp++) {  // a group longer than a tile
-    const uint32_t gs = A.grp_ptr[grp], ge = A.grp_ptr[grp + 1];
-    double acc = 0.0;
-    for (uint32_t lo = gs; lo < ge;) {
-      const uint32_t hi = min(ge, lo + TILE);
-      __syncthreads();
-      coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod);
-      __syncthreads();
-      if (threadIdx.x == 0)
-        for (uint32_t j = lo; j < hi; j++) acc += s_prod[j - lo];
-      lo = hi;
+  } else {
+    for (uint32_t grp = g0; grp < g1; grp++) {  // a group longer than a tile
+      const uint32_t gs = A.grp_ptr[grp], ge = A.grp_ptr[grp + 1];
+      double acc = 0.0;
+      for (uint32_t lo = gs; lo < ge;) {
+        const uint32_t hi = min(ge, lo + TILE);
+        __syncthreads();
+        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod);
+        __syncthreads();
+        if (threadIdx.x == 0)
+          for (uint32_t j = lo; j < hi; j++) acc += s_prod[j - lo];
+        lo = hi;
+      }
+      if (threadIdx.x == 0) {
+        y[grp] = acc;
+        if (FUSE) dsum += x[grp] * acc;
+      }
     }
-    if (threadIdx.x == 0) y[grp] = acc;
   }
+  if (FUSE) fused_dot_finish(dsum, fuse);
 }
 
 template <int MODE>
 static hipError_t launch_spmv_coo_mode(const CooDev &A, const double *x, double *y, EventRing ev,
-                                       hipStream_t s) {
-  hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A, x,
-                     y, ev);
+                                       const FuseOut *fuse, hipStream_t s) {
+  if (fuse) {
+    hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT, true>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, *fuse);
+  } else
+    hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT, false>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, FuseOut{});
   return hipGetLastError();
 }
 
 hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
-                           hipStream_t s) {
+                           const FuseOut *fuse, hipStream_t s) {
   if (A.nblk == 0) return hipSuccess;
   switch (mode) {
-    case MODE_NONE: return launch_spmv_coo_mode<MODE_NONE>(A, x, y, ev, s);
-    case MODE_CONSTRAINTS: return launch_spmv_coo_mode<MODE_CONSTRAINTS>(A, x, y, ev, s);
-    case MODE_SED: return launch_spmv_coo_mode<MODE_SED>(A, x, y, ev, s);
-    case MODE_SEC7: return launch_spmv_coo_mode<MODE_SEC7>(A, x, y, ev, s);
-    case MODE_SEC8: return launch_spmv_coo_mode<MODE_SEC8>(A, x, y, ev, s);
-    case MODE_SECDED: return launch_spmv_coo_mode<MODE_SECDED>(A, x, y, ev, s);
+    case MODE_NONE: return launch_spmv_coo_mode<MODE_NONE>(A, x, y, ev, fuse, s);
+    case MODE_CONSTRAINTS: return launch_spmv_coo_mode<MODE_CONSTRAINTS>(A, x, y, ev, fuse, s);
+    case MODE_SED: return launch_spmv_coo_mode<MODE_SED>(A, x, y, ev, fuse, s);
+    case MODE_SEC7: return launch_spmv_coo_mode<MODE_SEC7>(A, x, y, ev, fuse, s);
+    case MODE_SEC8: return launch_spmv_coo_mode<MODE_SEC8>(A, x, y, ev, fuse, s);
+    case MODE_SECDED: return launch_spmv_coo_mode<MODE_SECDED>(A, x, y, ev, fuse, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -542,11 +633,66 @@ int reduce_blocks(int n) {
   return (int)nb;
 }
 
-// dot, stage 1 (reference CSR/CPUContext.cpp:82-90).  VEC=2: 16-byte loads.
+// Second half of every reduction, run by all blocks after their block_sum:
+// publish the partial, take a ticket, and let the last arriver combine.
+// Inter-workgroup hand-off per the CDNA4 rules, in the cheap form: the partial
+// goes out with a write-through (sc1) store -- an agent-scope RELEASE fence here
+// would write back every dirty L2 line of the XCD in every block (measured: dot
+// 27 -> 81 us, calc_xr 76 -> 175 us) -- the storing lane drains it
+// (s_waitcnt vmcnt(0)) before its relaxed agent-scope ticket add; only the last
+// arriver pays one agent-scope acquire, drained before the workgroup barrier
+// that lets the other lanes read the partials (with sc1 loads).
+__device__ __forceinline__ void reduce_finish(double block_value, const ReduceOut &o, double *s_w) {
+  __shared__ uint32_t s_last;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(o.partials + blockIdx.x, block_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // two-level arrival: atomics on one address retire one per ~12 ns, so 2048
+    // blocks on a single counter cost ~25 us; 32 per group counter (the groups run
+    // in parallel) and one top-level add per group cost ~1 us
+    const uint32_t g = blockIdx.x / ABFT_TICKET_GROUP, ngroups = (gridDim.x + ABFT_TICKET_GROUP - 1u) / ABFT_TICKET_GROUP;
+    const uint32_t gsize = min((uint32_t)ABFT_TICKET_GROUP, gridDim.x - g * ABFT_TICKET_GROUP);
+    uint32_t last = 0u;
+    if (__hip_atomic_fetch_add(o.ticket + 1u + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+      __hip_atomic_store(o.ticket + 1u + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = __hip_atomic_fetch_add(o.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u ? 1u : 0u;
+    }
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  double acc = 0.0;
+  for (uint32_t i = threadIdx.x; i < gridDim.x; i += ABFT_BLOCK)  // fixed order
+    acc += __hip_atomic_load(o.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  acc = block_sum(acc, s_w);
+  if (threadIdx.x == 0) {
+    const uint32_t nev = __hip_atomic_load(o.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o.dev_out) {  // shard-local form: {partial sum, queued events} for one all-reduce
+      o.dev_out[0] = acc;
+      o.dev_out[1] = (double)nev;
+    }
+    __hip_atomic_store(o.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    if (o.host) {
+      // write-through system-scope stores, drained, then the sequence number: the
+      // host sees {value, evcount} before seq without a release fence (which would
+      // first write back every dirty line calc_xr left in this XCD's L2)
+      __hip_atomic_store(&o.host->value, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&o.host->evcount, nev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&o.host->seq, o.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// dot (reference CSR/CPUContext.cpp:82-90).  VEC=2: 16-byte loads.
 template <int VEC>
 __global__ __launch_bounds__(ABFT_BLOCK) void dot_kernel(const double *__restrict__ a,
                                                          const double *__restrict__ b, int n,
-                                                         double *__restrict__ partials) {
+                                                         ReduceOut out) {
   __shared__ double s_w[4];
   double acc = 0.0;
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
@@ -561,16 +707,16 @@ __global__ __launch_bounds__(ABFT_BLOCK) void dot_kernel(const double *__restric
     }
   }
   acc = block_sum(acc, s_w);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  reduce_finish(acc, out, s_w);
 }
 
-// calc_xr, stage 1 (reference CSR/CPUContext.cpp:92-105): x += alpha p;
-// r -= alpha w; partial of r.r with the updated r.
+// calc_xr (reference CSR/CPUContext.cpp:92-105): x += alpha p; r -= alpha w;
+// r.r with the updated r.
 template <int VEC>
 __global__ __launch_bounds__(ABFT_BLOCK) void calc_xr_kernel(double *__restrict__ x, double *__restrict__ r,
                                                              const double *__restrict__ p,
                                                              const double *__restrict__ w, double alpha,
-                                                             int n, double *__restrict__ partials) {
+                                                             int n, ReduceOut out) {
   __shared__ double s_w[4];
   double acc = 0.0;
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
@@ -595,28 +741,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_xr_kernel(double *__restrict_
     }
   }
   acc = block_sum(acc, s_w);
-  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
-}
-
-// stage 2: one block adds the partials in a fixed order and publishes the
-// scalar (and the event count, so a queued ECC event reaches the host with the
-// same synchronisation that returns the dot product).
-__global__ __launch_bounds__(ABFT_BLOCK) void finalize_kernel(const double *__restrict__ partials, int nparts,
-                                                              double *dev_out, double *host_out,
-                                                              const uint32_t *ev_count,
-                                                              uint32_t *host_evcount) {
-  __shared__ double s_w[4];
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += ABFT_BLOCK) acc += partials[i];
-  acc = block_sum(acc, s_w);
-  if (threadIdx.x == 0) {
-    if (dev_out) {  // shard-local form: {partial sum, queued events} for one all-reduce
-      dev_out[0] = acc;
-      dev_out[1] = ev_count ? (double)*ev_count : 0.0;
-    }
-    if (host_out) *host_out = acc;
-    if (host_evcount && ev_count) *host_evcount = *ev_count;
-  }
+  reduce_finish(acc, out, s_w);
 }
 
 // calc_p (reference CSR/CPUContext.cpp:107-113): p = r + beta p
@@ -642,29 +767,22 @@ static inline bool aligned16(const void *a, const void *b = nullptr, const void 
   return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d) & 15u) == 0;
 }
 
-hipError_t launch_dot(const double *a, const double *b, int n, double *partials, hipStream_t s) {
+hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s) {
   const int nb = reduce_blocks(n);
   if (aligned16(a, b))
-    hipLaunchKernelGGL(dot_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, a, b, n, partials);
+    hipLaunchKernelGGL(dot_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, a, b, n, out);
   else
-    hipLaunchKernelGGL(dot_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, a, b, n, partials);
+    hipLaunchKernelGGL(dot_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, a, b, n, out);
   return hipGetLastError();
 }
 
 hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w, double alpha, int n,
-                          double *partials, hipStream_t s) {
+                          const ReduceOut &out, hipStream_t s) {
   const int nb = reduce_blocks(n);
   if (aligned16(x, r, p, w))
-    hipLaunchKernelGGL(calc_xr_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, partials);
+    hipLaunchKernelGGL(calc_xr_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, out);
   else
-    hipLaunchKernelGGL(calc_xr_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, partials);
-  return hipGetLastError();
-}
-
-hipError_t launch_finalize(const double *partials, int nparts, double *dev_out, double *host_out,
-                           const uint32_t *ev_count, uint32_t *host_evcount, hipStream_t s) {
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(ABFT_BLOCK), 0, s, partials, nparts, dev_out, host_out,
-                     ev_count, host_evcount);
+    hipLaunchKernelGGL(calc_xr_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, out);
   return hipGetLastError();
 }
 

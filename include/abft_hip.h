@@ -198,10 +198,14 @@ typedef enum {
   ABFT_K_COUNT = 4
 } abft_kernel_id;
 
-/* When enabled, every launch of the four CG kernels is bracketed by HIP
- * events on the context's stream.  abft_hip_profile_read synchronises and
- * returns the summed device time (ms) and launch count since the last reset. */
-int abft_hip_profile_enable(abft_hip_ctx *ctx, int on);
+/* `mask` bit k (1 << abft_kernel_id) brackets every launch of kernel k with HIP
+ * events on the context's stream; 0 switches profiling off.  A bracket costs
+ * two event records per launch, so measure throughput with only the kernel of
+ * interest enabled.  abft_hip_profile_read synchronises and returns the summed
+ * device time (ms) and launch count since the last reset.  With the fused dot
+ * (spmv on a square matrix), ABFT_K_DOT times the one-block fold that is left
+ * of dot(p, w). */
+int abft_hip_profile_enable(abft_hip_ctx *ctx, int mask);
 int abft_hip_profile_reset(abft_hip_ctx *ctx);
 int abft_hip_profile_read(abft_hip_ctx *ctx, int kernel, double *total_ms, long *launches);
 

@@ -405,3 +405,47 @@ def test_fatal_event_prints_reference_line_and_exits(amd, capfd):
         assert capfd.readouterr().out == "[ECC] error detected at index 123\n"
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+def test_fused_dot_is_transparent(amd, fmt):
+    """spmv(A,p,w) on a square matrix also forms p.w, so the dot(p,w) that follows
+    costs no kernel (cross-call fusion behind the unchanged API).  The value must
+    be a correct dot product whenever it is served, and must never be served
+    after either vector changed."""
+    cols, rows, vals, n = MATS["ragged"]()
+    rng = np.random.default_rng(5)
+    p, q = rng.standard_normal(n), rng.standard_normal(n)
+    ctx = amd.HIPContext("secded", FNAME[fmt])
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        vp, vw, vq = (ctx.create_vector(n) for _ in range(3))
+        ctx.upload(vp, p)
+        ctx.upload(vq, q)
+        ctx.spmv(A, vp, vw)
+        fused = ctx.dot(vp, vw)  # served by the SpMV
+        w = ctx.download(vw)
+        scale = float(np.abs(p * w).sum())
+        assert abs(fused - ora_dot(p, w)) <= 1e-13 * scale
+        assert ctx.dot(vw, vp) == fused  # either order, repeatable
+        other = ctx.dot(vq, vq)  # another reduction reuses the result slot
+        assert abs(other - ora_dot(q, q)) <= 1e-13 * float((q * q).sum())
+        assert ctx.dot(vp, vw) == fused  # still the cached value: nothing changed
+        ctx.calc_p(vp, vq, 0.5)  # p changes -> the cached product is stale
+        p2 = ctx.download(vp)
+        d2 = ctx.dot(vp, vw)
+        assert abs(d2 - ora_dot(p2, w)) <= 1e-13 * float(np.abs(p2 * w).sum())
+        assert d2 != fused
+        ctx.spmv(A, vp, vw)
+        ctx.upload(vw, w)  # w overwritten between spmv and dot -> must not be served
+        d3 = ctx.dot(vp, vw)
+        assert abs(d3 - ora_dot(p2, w)) <= 1e-13 * float(np.abs(p2 * w).sum())
+        # a fused SpMV that raises an ECC event still reports it with the dot
+        seen = []
+        ctx.on_event = lambda ev, fatal: seen.extend(ev)
+        ctx.inject_at(A, 3, [5])
+        ctx.spmv(A, vp, vw)
+        ctx.dot(vp, vw)
+        assert seen == [(2, 3, 5)]
+    finally:
+        ctx.close()
