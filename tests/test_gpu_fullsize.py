@@ -1,0 +1,206 @@
+"""Parity at BASELINE.json's full sizes, through properties that do not need a
+second implementation at that size (plus one oracle CG run, which the CPU
+finishes in seconds):
+
+  config 2/3  CSR, 5-point Laplacian 3162 x 3162 (N = 9 998 244, nnz = 49 978 572)
+  config 4    CSR, random:4194304,24 (nnz ~ 104.9 M), secded
+  config 5    COO, powerlaw:2097152 (nnz ~ 26 M), sec7
+
+Properties: A.1 equals the analytic row sums bit-for-bit; scaling x by 2 scales y
+by 2 bit-for-bit; CSR and COO give bit-identical y on a symmetric matrix (the
+reference's two executables do); x.(A z) = z.(A x); injected
+single-bit flips at full size are each reported once with the right global
+index, repaired in place, and leave y bit-identical to the fault-free y."""
+import numpy as np
+import pytest
+
+from _oracle import CSR, OracleMatrix
+
+pytestmark = pytest.mark.gpu
+
+LAP = "laplace5:3162,3162"
+NX = 3162
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import abft_sparse_cg_amd as a
+    return a
+
+
+@pytest.fixture(scope="module")
+def gen():
+    from abft_sparse_cg_amd import generators
+    return generators
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+class Run:
+    def __init__(self, amd, fmt, mode, mat):
+        cols, rows, vals, n = mat
+        self.events = []
+        self.ctx = amd.HIPContext(mode, fmt, on_event=lambda ev, fatal: self.events.extend(ev))
+        self.A = self.ctx.create_matrix(cols, rows, vals, n, len(vals))
+        self.n = n
+        self.vx, self.vy = self.ctx.create_vector(n), self.ctx.create_vector(n)
+
+    def spmv(self, x):
+        self.ctx.upload(self.vx, x)
+        self.ctx.spmv(self.A, self.vx, self.vy)
+        return self.ctx.download(self.vy)
+
+    def close(self):
+        self.ctx.close()
+
+
+def laplace_row_sums(nx, ny):
+    i = np.arange(nx * ny)
+    ix, iy = i % nx, i // nx
+    nb = (ix > 0).astype(float) + (ix < nx - 1) + (iy > 0) + (iy < ny - 1)
+    return 4.0 - nb
+
+
+def test_config2_laplacian_properties_all_modes(amd, gen):
+    mat = gen.generate(LAP)
+    cols, rows, vals, n = mat
+    assert n == 9998244 and len(vals) == 49978572
+    rng = np.random.default_rng(3)
+    x, z = rng.standard_normal(n), rng.standard_normal(n)
+    want_ones = laplace_row_sums(NX, NX)
+    y_ref = None
+    for fmt, mode in (("csr", "none"), ("csr", "secded"), ("csr", "sed"), ("coo", "sec8"), ("csr", "constraints")):
+        r = Run(amd, fmt, mode, mat)
+        try:
+            assert bits_equal(r.spmv(np.ones(n)), want_ones), (fmt, mode)
+            y = r.spmv(x)
+            if y_ref is None:
+                y_ref = y
+                # independent check of y on a slice of rows, in float64 with the same order of operations
+                for row in (0, 1, NX, n // 2, n - 1):
+                    lo, hi = np.searchsorted(rows, row), np.searchsorted(rows, row + 1)
+                    acc = 0.0
+                    for k in range(lo, hi):
+                        acc += vals[k] * x[cols[k]]
+                    assert y[row] == acc
+            assert bits_equal(y, y_ref), (fmt, mode)  # every mode and both formats: identical bits
+            assert bits_equal(r.spmv(2.0 * x), 2.0 * y)
+            assert r.events == []
+            if fmt == "csr" and mode == "none":
+                yz = r.spmv(z)
+                a, b = float(np.dot(z, y)), float(np.dot(x, yz))
+                assert abs(a - b) <= 1e-11 * np.abs(z * y).sum()
+        finally:
+            r.close()
+
+
+def test_config3_full_size_flip_round_trip(amd, gen):
+    """sed detects at full size; secded repairs value, index and check-bit flips
+    spread over the whole matrix, once each, and y is unchanged."""
+    mat = gen.generate(LAP)
+    cols, rows, vals, n = mat
+    nnz = len(vals)
+    x = np.random.default_rng(4).standard_normal(n)
+    r = Run(amd, "csr", "secded", mat)
+    try:
+        y0 = r.spmv(x)
+        flips = [(0, 0), (1, 63), (nnz // 3, 64), (nnz // 2, 80), (nnz - 1, 95), (12345678, 88), (nnz - 2, 37)]
+        for idx, bit in flips:
+            r.ctx.inject_at(r.A, idx, [bit])
+        y1 = r.spmv(x)
+        got = sorted(r.events)
+        want = sorted((3, idx, 0) if bit == 88 else (2, idx, bit) for idx, bit in flips)
+        assert got == want
+        assert bits_equal(y1, y0)
+        r.events.clear()
+        assert bits_equal(r.spmv(x), y0) and r.events == []  # repaired in place: silent now
+        r.ctx.inject_at(r.A, 7777777, [3, 70])
+        r.spmv(x)
+        assert r.events == [(4, 7777777, 0)]
+    finally:
+        r.close()
+    s = Run(amd, "csr", "sed", mat)
+    try:
+        s.ctx.inject_at(s.A, nnz - 5, [66])
+        s.spmv(x)
+        assert s.events == [(1, nnz - 5, 0)]
+    finally:
+        s.close()
+
+
+def test_config2_cg_history_matches_oracle_at_full_size(amd, gen):
+    mat = gen.generate(LAP)
+    cols, rows, vals, n = mat
+    b = np.random.default_rng(1).random(n)
+    iters = 25
+    o = OracleMatrix(CSR, "none", cols, rows, vals, n)
+    it_o, hist_o, x_o, _ = o.cg(b, max_itrs=iters, conv=0.0, threads=8)
+    o.close()
+    ctx = amd.HIPContext("none", "csr")
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        vb, vx, vr, vp, vw = (ctx.create_vector(n) for _ in range(5))
+        ctx.upload(vb, b)
+        ctx.upload(vx, np.zeros(n))
+        hist = []
+        it, rr = amd.cg_solve(ctx, A, vb, vx, vr, vp, vw, max_itrs=iters, conv_threshold=0.0,
+                              on_iteration=lambda i, r: hist.append(r))
+        assert it == it_o == iters
+        assert np.allclose(hist, hist_o, rtol=1e-10, atol=0)
+        x = ctx.download(vx)
+        assert np.abs(x - x_o).max() <= 1e-10 * np.abs(x_o).max()
+    finally:
+        ctx.close()
+
+
+def test_config4_random_csr_secded_full_size(amd, gen):
+    mat = gen.generate("random:4194304,24,1")
+    cols, rows, vals, n = mat
+    assert n == 1 << 22 and 100e6 < len(vals) < 110e6
+    x = np.random.default_rng(6).standard_normal(n)
+    r = Run(amd, "csr", "secded", mat)
+    try:
+        y = r.spmv(x)
+        # strictly diagonally dominant rows: A.1 = 1 + (rounding of the row sum), checked in exact order on sample rows
+        for row in (0, 17, n // 2, n - 1):
+            lo, hi = np.searchsorted(rows, row), np.searchsorted(rows, row + 1)
+            acc = 0.0
+            for k in range(lo, hi):
+                acc += vals[k] * x[cols[k]]
+            assert y[row] == acc
+        assert bits_equal(r.spmv(0.5 * x), 0.5 * y)
+        r.ctx.inject_at(r.A, len(vals) - 1, [90])
+        r.ctx.inject_at(r.A, 50000000, [11])
+        assert bits_equal(r.spmv(x), y)
+        assert sorted(r.events) == [(2, 50000000, 11), (2, len(vals) - 1, 90)]
+    finally:
+        r.close()
+    c = Run(amd, "coo", "secded", mat)
+    try:
+        assert bits_equal(c.spmv(x), y)  # symmetric matrix: COO sums in the same order as CSR
+    finally:
+        c.close()
+
+
+def test_config5_powerlaw_coo_sec7_full_size(amd, gen):
+    mat = gen.generate("powerlaw:2097152,2")
+    cols, rows, vals, n = mat
+    x = np.random.default_rng(7).standard_normal(n)
+    c = Run(amd, "coo", "sec7", mat)
+    k = Run(amd, "csr", "sec7", mat)
+    try:
+        y = c.spmv(x)
+        assert bits_equal(y, k.spmv(x))
+        for row in (0, 5, n - 1):
+            lo, hi = np.searchsorted(rows, row), np.searchsorted(rows, row + 1)
+            acc = 0.0
+            for j in range(lo, hi):
+                acc += vals[j] * x[cols[j]]
+            assert y[row] == acc
+        c.ctx.inject_at(c.A, 1000003, [100])
+        assert bits_equal(c.spmv(x), y) and c.events == [(2, 1000003, 100)]
+    finally:
+        c.close()
+        k.close()
