@@ -181,14 +181,17 @@ __device__ __forceinline__ void fused_dot_finish(double dsum, const FuseOut &f) 
 
 __global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t nblk) {
   __shared__ double s_w[16];
-  // fixed order; four independent loads in flight per thread
+  // fixed order; sixteen independent loads in flight per thread
   double acc = 0.0;
-  for (uint32_t i = threadIdx.x; i < nblk; i += 4096u) {
-    const double a0 = f.partials[i];
-    const double a1 = i + 1024u < nblk ? f.partials[i + 1024u] : 0.0;
-    const double a2 = i + 2048u < nblk ? f.partials[i + 2048u] : 0.0;
-    const double a3 = i + 3072u < nblk ? f.partials[i + 3072u] : 0.0;
-    acc += (a0 + a1) + (a2 + a3);
+  for (uint32_t i = threadIdx.x; i < nblk; i += 16u * 1024u) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      const uint32_t j = i + (uint32_t)k * 1024u;
+      v[k] = j < nblk ? f.partials[j] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) acc += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
   }
   acc = wave_sum(acc);
   if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = acc;

@@ -1,19 +1,26 @@
+#!/bin/bash
+# Collects the round-1 rocprofv3 evidence on the GPU box (run via gpurun from the repo root):
+#   kernel trace + stats of the default bench.py workload, then separate PMC passes
+#   (FETCH_SIZE / WRITE_SIZE / TCC hit-miss) as the MI355X guide prescribes, for the
+#   Laplacian (config 2) and the random matrix (config 4).  Raw CSVs stay in gpurun_out/;
+#   the summaries written next to them are what gets copied into profiles/r01/.
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/prof_r01
-mkdir -p $O
-rocprofv3 --kernel-trace --stats -f csv -d $O/trace -- python3 bench.py --cpu-iters 0 --steps 100 > $O/bench_under_trace.json 2> $O/trace.err
+rm -rf $O; mkdir -p $O
+B="python3 bench.py --cpu-iters 0"
+rocprofv3 --kernel-trace --stats -f csv -d $O/trace -- $B --steps 100 > $O/bench_under_trace.json 2> $O/trace.err
 python3 profiles/summarize.py trace $O/trace $O/kernel_trace_laplace_none.md
-rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch -- python3 bench.py --cpu-iters 0 --steps 10 --warmup 2 --no-profile > /dev/null 2> $O/pmc_fetch.err
-python3 profiles/summarize.py pmc $O/pmc_fetch $O/pmc_fetch_laplace_none.json
-rocprofv3 --pmc WRITE_SIZE -f csv -d $O/pmc_write -- python3 bench.py --cpu-iters 0 --steps 10 --warmup 2 --no-profile > /dev/null 2> $O/pmc_write.err
-python3 profiles/summarize.py pmc $O/pmc_write $O/pmc_write_laplace_none.json
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -f csv -d $O/pmc_tcc -- python3 bench.py --cpu-iters 0 --steps 10 --warmup 2 --no-profile > /dev/null 2> $O/pmc_tcc.err
-python3 profiles/summarize.py pmc $O/pmc_tcc $O/pmc_tcc_laplace_none.json
-rocprofv3 --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_rand -- python3 bench.py --cpu-iters 0 --steps 5 --warmup 1 --no-profile --mode secded --spec random:4194304,24,1 > /dev/null 2> $O/pmc_fetch_rand.err
-python3 profiles/summarize.py pmc $O/pmc_fetch_rand $O/pmc_fetch_random_secded.json
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -f csv -d $O/pmc_tcc_rand -- python3 bench.py --cpu-iters 0 --steps 5 --warmup 1 --no-profile --mode secded --spec random:4194304,24,1 > /dev/null 2> $O/pmc_tcc_rand.err
-python3 profiles/summarize.py pmc $O/pmc_tcc_rand $O/pmc_tcc_random_secded.json
-rm -rf $O/trace $O/pmc_fetch $O/pmc_write $O/pmc_tcc $O/pmc_fetch_rand $O/pmc_tcc_rand
-ls -la $O
+rocprofv3 --kernel-trace --stats -f csv -d $O/trace_secded -- $B --steps 100 --mode secded > $O/bench_under_trace_secded.json 2> $O/trace2.err
+python3 profiles/summarize.py trace $O/trace_secded $O/kernel_trace_laplace_secded.md
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
+  n=$(echo $c | cut -d' ' -f1 | tr A-Z a-z)
+  rocprofv3 --pmc $c -f csv -d $O/pmc_$n -- $B --steps 10 --warmup 2 --no-profile > /dev/null 2> $O/pmc_$n.err
+  python3 profiles/summarize.py pmc $O/pmc_$n $O/pmc_${n}_laplace_none.json > /dev/null
+  rocprofv3 --pmc $c -f csv -d $O/pmcr_$n -- $B --steps 5 --warmup 1 --no-profile --mode secded --spec random:4194304,24,1 > /dev/null 2> $O/pmcr_$n.err
+  python3 profiles/summarize.py pmc $O/pmcr_$n $O/pmc_${n}_random_secded.json > /dev/null
+done
+rm -rf $O/trace $O/trace_secded $O/pmc_fetch_size $O/pmc_write_size $O/pmc_tcc_hit_sum $O/pmcr_fetch_size $O/pmcr_write_size $O/pmcr_tcc_hit_sum
+cat $O/kernel_trace_laplace_none.md
+ls $O
