@@ -45,6 +45,7 @@ struct ProfSlot {
 
 struct abft_hip_ctx {
   int device = 0;
+  int num_cus = 256;
   hipStream_t own_stream = nullptr, stream = nullptr;
   double *partials = nullptr;  // ABFT_MAX_PARTIALS doubles
   uint32_t *ticket = nullptr;  // reduction arrival counter (device)
@@ -74,6 +75,9 @@ struct abft_hip_matrix {
   CsrDev csr{};
   CooDev coo{};
   double *fuse_partials = nullptr;  // FuseOut buffer (square matrices)
+  bool use_panels = false;          // CSR only: panel layout chosen at create time
+  CsrPanels panels{};
+  uint32_t panel_grid = 0;          // persistent workgroups of the panel kernel
   std::vector<void *> allocs;
 };
 
@@ -167,6 +171,7 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   abft_hip_ctx *ctx = new (std::nothrow) abft_hip_ctx();
   if (!ctx) return set_err(ABFT_ERR_NOMEM, "context allocation failed");
   ctx->device = device;
+  ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
   ctx->stream = ctx->own_stream;
   HIPCHK(hipMalloc((void **)&ctx->partials, ABFT_MAX_PARTIALS * sizeof(double)));
@@ -259,6 +264,67 @@ static void cut_blocks(const uint32_t *ptr, uint32_t n, uint32_t tile, bool alig
   }
 }
 
+// ---- panel layout planning (host) ----------------------------------------------
+
+struct PanelBuild {
+  uint32_t ngroups = 0, npanels = 0, width = 0;
+  std::vector<uint32_t> seg_base;  // nseg + 1
+  std::vector<uint16_t> seg_ptr;   // nseg * (ABFT_PANEL_ROWS + 1)
+  std::vector<uint32_t> pos, orig; // caller's index -> storage position and back
+};
+
+// Decide whether the panel layout pays for this matrix and, if so, build it.
+// It pays when the input vector is much larger than an XCD's L2 and a row group
+// reaches into several panels (scattered columns); banded matrices keep the
+// streaming layout, whose x window already lives in L2.  Needs columns ascending
+// within a row (as the reference loader delivers them): panels are swept in
+// ascending order, so the additions of a row then happen in the caller's order.
+// ABFT_HIP_LAYOUT=stream|panels|auto and ABFT_HIP_PANEL_WIDTH (entries) override.
+static bool plan_panels(int mode, const uint32_t *columns, const uint32_t *rows, int n_out, int n_in, int nnz,
+                        PanelBuild &pb) {
+  const char *env = getenv("ABFT_HIP_LAYOUT");
+  const bool force = env && !strcmp(env, "panels");
+  if ((env && !strcmp(env, "stream")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0) return false;
+  uint32_t width = 1u << 18;  // 2 MB of x per panel: two panels fit an XCD's 4 MB L2
+  if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
+  if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
+  const uint64_t ngroups = ((uint64_t)n_out + ABFT_PANEL_ROWS - 1) / ABFT_PANEL_ROWS;
+  const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
+  const uint64_t nseg = ngroups * npanels;
+  if (nseg == 0 || nseg > ((uint64_t)1 << 27)) return false;
+  for (int i = 1; i < nnz; i++)
+    if (rows[i] == rows[i - 1] && columns[i] < columns[i - 1]) return false;  // would reorder a row's additions
+  pb.ngroups = (uint32_t)ngroups; pb.npanels = (uint32_t)npanels; pb.width = width;
+  pb.seg_base.assign(nseg + 1, 0);
+  for (int i = 0; i < nnz; i++) {
+    const uint64_t seg = (uint64_t)(rows[i] / ABFT_PANEL_ROWS) * npanels + std::min<uint64_t>(columns[i] / width, npanels - 1);
+    pb.seg_base[seg + 1]++;
+  }
+  uint64_t nonempty = 0;
+  for (uint64_t sgm = 0; sgm < nseg; sgm++) {
+    if (pb.seg_base[sgm + 1] > 65535u) return false;  // 16-bit row offsets
+    nonempty += pb.seg_base[sgm + 1] != 0;
+  }
+  if (!force && nonempty < 3 * ngroups) return false;  // a row group stays within a panel or two: banded
+  for (uint64_t sgm = 0; sgm < nseg; sgm++) pb.seg_base[sgm + 1] += pb.seg_base[sgm];
+  pb.pos.resize((size_t)nnz);
+  pb.orig.resize((size_t)nnz);
+  pb.seg_ptr.assign(nseg * (ABFT_PANEL_ROWS + 1), 0);
+  std::vector<uint32_t> fill(pb.seg_base.begin(), pb.seg_base.end() - 1);
+  for (int i = 0; i < nnz; i++) {
+    const uint64_t seg = (uint64_t)(rows[i] / ABFT_PANEL_ROWS) * npanels + std::min<uint64_t>(columns[i] / width, npanels - 1);
+    const uint32_t p = fill[seg]++;
+    pb.pos[i] = p;
+    pb.orig[p] = (uint32_t)i;
+    pb.seg_ptr[seg * (ABFT_PANEL_ROWS + 1) + rows[i] % ABFT_PANEL_ROWS + 1]++;
+  }
+  for (uint64_t sgm = 0; sgm < nseg; sgm++) {
+    uint16_t *p = pb.seg_ptr.data() + sgm * (ABFT_PANEL_ROWS + 1);
+    for (int r = 0; r < ABFT_PANEL_ROWS; r++) p[r + 1] = (uint16_t)(p[r + 1] + p[r]);
+  }
+  return true;
+}
+
 static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, const uint32_t *rows,
                       const double *values, int n_out, int n_in, int nnz, uint32_t index_base,
                       abft_hip_matrix **out) {
@@ -288,13 +354,48 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   CsrDev &A = m->csr;
   A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
   A.nblk = (uint32_t)blk.size();
+  A.orig_index = nullptr;
+  A.pos_of_orig = nullptr;
   const size_t padded = ((size_t)nnz + 3) & ~(size_t)1;  // even, >= nnz + 2
   int rc;
   uint32_t *d_rowptr = nullptr;
   uint4 *d_blk = nullptr;
-  if ((rc = dev_upload(m, &A.cols, columns, (size_t)nnz, padded)) ||
-      (rc = dev_upload(m, &A.vals, values, (size_t)nnz, padded)) ||
-      (rc = dev_upload(m, &d_rowptr, rowptr.data(), rowptr.size(), rowptr.size())) ||
+
+  // ---- layout: streaming row blocks (default) or column panels (scattered x) ----
+  PanelBuild pb;
+  const bool panels = plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);
+  if (panels) {
+    std::vector<uint32_t> pcols((size_t)nnz);
+    std::vector<double> pvals((size_t)nnz);
+    for (int i = 0; i < nnz; i++) {
+      pcols[pb.pos[i]] = columns[i];
+      pvals[pb.pos[i]] = values[i];
+    }
+    uint32_t *d_segbase = nullptr, *d_orig = nullptr, *d_pos = nullptr;
+    uint16_t *d_segptr = nullptr;
+    if ((rc = dev_upload(m, &A.cols, pcols.data(), (size_t)nnz, padded)) ||
+        (rc = dev_upload(m, &A.vals, pvals.data(), (size_t)nnz, padded)) ||
+        (rc = dev_upload(m, &d_segbase, pb.seg_base.data(), pb.seg_base.size(), pb.seg_base.size())) ||
+        (rc = dev_upload(m, &d_segptr, pb.seg_ptr.data(), pb.seg_ptr.size(), pb.seg_ptr.size())) ||
+        (rc = dev_upload(m, &d_orig, pb.orig.data(), (size_t)nnz, (size_t)nnz)) ||
+        (rc = dev_upload(m, &d_pos, pb.pos.data(), (size_t)nnz, (size_t)nnz))) {
+      matrix_free(m);
+      return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // pcols/pvals go out of scope
+    A.orig_index = d_orig;
+    A.pos_of_orig = d_pos;
+    m->use_panels = true;
+    m->panels.seg_base = d_segbase;
+    m->panels.seg_ptr = d_segptr;
+    m->panels.ngroups = pb.ngroups;
+    m->panels.npanels = pb.npanels;
+  } else if ((rc = dev_upload(m, &A.cols, columns, (size_t)nnz, padded)) ||
+             (rc = dev_upload(m, &A.vals, values, (size_t)nnz, padded))) {
+    matrix_free(m);
+    return rc;
+  }
+  if ((rc = dev_upload(m, &d_rowptr, rowptr.data(), rowptr.size(), rowptr.size())) ||
       (rc = dev_upload(m, &d_blk, blk.data(), blk.size(), blk.size()))) {
     matrix_free(m);
     return rc;
@@ -383,8 +484,12 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
   if (rc != ABFT_OK) return rc;
   abft_hip_matrix *m = *out;
   const uint32_t nblk = format == ABFT_FMT_CSR ? m->csr.nblk : m->coo.nblk;
+  if (m->use_panels) {
+    const int per_cu = spmv_csr_panels_blocks_per_cu(mode, true);
+    m->panel_grid = std::min<uint32_t>(m->panels.ngroups, (uint32_t)(per_cu * ctx->num_cus));
+  }
   if (n_out == n_in && nblk > 0) {  // square: spmv can also deliver vec.result
-    if (hipMalloc((void **)&m->fuse_partials, (size_t)nblk * sizeof(double)) != hipSuccess) {
+    if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(nblk, 4096) * sizeof(double)) != hipSuccess) {
       matrix_free(m);
       *out = nullptr;
       return set_err(ABFT_ERR_NOMEM, "fusion buffer for %u blocks does not fit", nblk);
@@ -427,10 +532,24 @@ extern "C" int abft_hip_matrix_read_csr(abft_hip_matrix *mat, uint32_t *cols, ui
   if (int rc = bind(mat->ctx)) return rc;
   hipStream_t s = mat->ctx->stream;
   const CsrDev &A = mat->csr;
-  if (cols && A.nnz) HIPCHK(hipMemcpyAsync(cols, A.cols, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
-  if (values && A.nnz) HIPCHK(hipMemcpyAsync(values, A.vals, (size_t)A.nnz * 8, hipMemcpyDeviceToHost, s));
   if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, A.rowptr, ((size_t)A.n_out + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (!mat->use_panels) {
+    if (cols && A.nnz) HIPCHK(hipMemcpyAsync(cols, A.cols, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
+    if (values && A.nnz) HIPCHK(hipMemcpyAsync(values, A.vals, (size_t)A.nnz * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return ABFT_OK;
+  }
+  // panel layout: stored order differs from the caller's; hand the arrays back in the caller's
+  std::vector<uint32_t> pc(A.nnz), orig(A.nnz);
+  std::vector<double> pv(A.nnz);
+  HIPCHK(hipMemcpyAsync(pc.data(), A.cols, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(pv.data(), A.vals, (size_t)A.nnz * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(orig.data(), A.orig_index, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  for (uint32_t p = 0; p < A.nnz; p++) {
+    if (cols) cols[orig[p]] = pc[p];
+    if (values) values[orig[p]] = pv[p];
+  }
   return ABFT_OK;
 }
 
@@ -463,7 +582,7 @@ extern "C" int abft_hip_inject(abft_hip_matrix *mat, uint32_t index, const int *
   abft_hip_ctx *ctx = mat->ctx;
   HIPCHK(hipMemcpyAsync(ctx->bits_dev, bits, (size_t)nbits * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   hipError_t e = mat->fmt == ABFT_FMT_CSR
-                     ? launch_inject_csr(mat->csr.vals, mat->csr.cols, index, ctx->bits_dev, nbits, ctx->stream)
+                     ? launch_inject_csr(mat->csr.vals, mat->csr.cols, mat->csr.pos_of_orig, index, ctx->bits_dev, nbits, ctx->stream)
                      : launch_inject_coo(mat->coo.elems, mat->coo.pos_of_orig, index, ctx->bits_dev, nbits, ctx->stream);
   HIPCHK(e);
   HIPCHK(hipStreamSynchronize(ctx->stream));  // `bits` is the caller's
@@ -677,16 +796,21 @@ extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft
     fuse.ev_count = ctx->ring.count;
     fuse.seq = ++ctx->seq;
   }
+  uint32_t nparts = mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk;
   {
     KernelTimer t(ctx, ABFT_K_SPMV);
-    if (mat->fmt == ABFT_FMT_CSR)
+    if (mat->fmt == ABFT_FMT_CSR && mat->use_panels) {
+      nparts = mat->panel_grid;
+      HIPCHK(launch_spmv_csr_panels(mat->mode, mat->csr, mat->panels, vec->d, result->d, ctx->ring,
+                                    do_fuse ? &fuse : nullptr, mat->panel_grid, ctx->stream));
+    } else if (mat->fmt == ABFT_FMT_CSR)
       HIPCHK(launch_spmv_csr(mat->mode, mat->csr, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
     else
       HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
   }
   if (do_fuse) {
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
-    HIPCHK(launch_fuse_finalize(fuse, mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk, ctx->stream));
+    HIPCHK(launch_fuse_finalize(fuse, nparts, ctx->stream));
   }
   if (do_fuse) {
     ctx->fused.valid = true;

@@ -22,7 +22,28 @@ struct CsrDev {
   const uint32_t *rowptr;   // n_out + 1
   const uint4 *blk;         // nblk : {first row, end row, first element, end element} of each row block
   uint32_t nblk, n_out, n_in, nnz, index_base;
+  // Panel layout only (see CsrPanels): elements are stored grouped by
+  // (row group, column panel); these map storage position <-> caller's index.
+  const uint32_t *orig_index;   // cold path: event messages carry the caller's element index
+  const uint32_t *pos_of_orig;  // inject
 };
+
+// Panel ("column-blocked") layout for matrices whose columns are scattered over
+// a vector much larger than an XCD's 4 MB L2 (random / unstructured).  Rows are
+// cut into groups of ABFT_PANEL_ROWS, columns into panels of `width` entries
+// (2 MB of x); the elements of one (row group, panel) segment are contiguous and
+// keep their (row, col) order.  A workgroup owns a row group, keeps the running
+// row sums in registers and sweeps the panels in ascending order -- the same
+// order of additions as the row-by-row sum, so y stays bit-identical -- while all
+// resident workgroups gather from the same 2 MB window of x at a time, which the
+// L2 then serves (the streaming layout misses L2 on 7 of 8 gathers here).
+struct CsrPanels {
+  const uint32_t *seg_base;  // ngroups * npanels + 1 : first element of each segment
+  const uint16_t *seg_ptr;   // per segment ABFT_PANEL_ROWS + 1 row offsets relative to seg_base
+  uint32_t ngroups, npanels;
+};
+constexpr int ABFT_PANEL_ROWS_PER_THREAD = 4;
+constexpr int ABFT_PANEL_ROWS = 256 * ABFT_PANEL_ROWS_PER_THREAD;
 
 // COO matrix: 16-byte elements {col,row,value} (COO/ecc.h:11-16) stored grouped
 // by output index (col) and, inside a group, in the caller's order -- so each
@@ -45,6 +66,9 @@ struct CooDev {
 #ifndef ABFT_CFG_COO_EPT
 #define ABFT_CFG_COO_EPT 4
 #endif
+#ifndef ABFT_CFG_PANEL_EPT
+#define ABFT_CFG_PANEL_EPT 8  // elements per thread per tile of the panel-layout kernel (4: -9%)
+#endif
 #ifndef ABFT_CFG_NT
 #define ABFT_CFG_NT 1  // stream cols/vals with the non-temporal hint
 #endif
@@ -66,8 +90,8 @@ constexpr int ABFT_TICKET_WORDS = 1 + ABFT_MAX_PARTIALS / ABFT_TICKET_GROUP;  //
 
 hipError_t launch_encode_csr(int mode, uint32_t *cols, double *vals, uint32_t nnz, hipStream_t s);
 hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s);
-hipError_t launch_inject_csr(double *vals, uint32_t *cols, uint32_t index, const int *bits_dev,
-                             int nbits, hipStream_t s);
+hipError_t launch_inject_csr(double *vals, uint32_t *cols, const uint32_t *pos_of_orig, uint32_t index,
+                             const int *bits_dev, int nbits, hipStream_t s);
 hipError_t launch_inject_coo(uint4 *elems, const uint32_t *pos_of_orig, uint32_t index,
                              const int *bits_dev, int nbits, hipStream_t s);
 
@@ -105,6 +129,10 @@ struct FuseOut {
   uint32_t seq;
 };
 
+// panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
+hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, hipStream_t s);
+int spmv_csr_panels_blocks_per_cu(int mode, bool fuse);
 // fuse == nullptr: plain SpMV; otherwise follow with launch_fuse_finalize
 hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s);
 hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,

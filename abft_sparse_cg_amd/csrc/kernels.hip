@@ -23,6 +23,20 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define STREAM_LOAD(p) (*(p))
 #endif
 
+// how the x-gather is issued: 0 plain (through the CU's L1), 1 non-temporal, 2 sc1 (L1 bypass)
+#ifndef ABFT_CFG_GATHER
+#define ABFT_CFG_GATHER 0
+#endif
+__device__ __forceinline__ double gather_load(const double *p) {
+#if ABFT_CFG_GATHER == 1
+  return __builtin_nontemporal_load(p);
+#elif ABFT_CFG_GATHER == 2
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  return *p;
+#endif
+}
+
 // ------------------------------------------------------------------ helpers --
 
 // Hardware deals consecutive workgroup ids round-robin over the 8 XCDs
@@ -252,7 +266,7 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
       if (__builtin_expect(valid && ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
         EccWords<FMT_CSR> e;
         e.w[0] = w[0]; e.w[1] = w[1]; e.w[2] = w[2]; e.rc = 0;
-        e = ecc_cold<FMT_CSR, MODE>(e, A.index_base + i, ev);
+        e = ecc_cold<FMT_CSR, MODE>(e, A.index_base + (A.orig_index ? A.orig_index[i] : i), ev);
         w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2];
         if (e.rc > 0) {  // reference CSR/CPUContext.cpp:275-276, 333-334, 389-390
           A.vals[i] = as_double(w[0], w[1]);
@@ -271,7 +285,7 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
 #pragma unroll
   for (int j = 0; j < EPT; j++) {
     const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
-    xv[j] = x[in ? col[j] : 0u];
+    xv[j] = gather_load(x + (in ? col[j] : 0u));
     xv[j] = in ? xv[j] : 0.0;
   }
 #pragma unroll
@@ -404,6 +418,112 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
   if (FUSE) fused_dot_finish(dsum, fuse);
 }
 
+// Panel-layout CSR SpMV (see CsrPanels).  Persistent workgroups: each takes row
+// groups g, g + gridDim.x, ... and, per group, sweeps the column panels in
+// ascending order with the 4 row sums of every thread held in registers.  A
+// segment is staged through LDS by the same branch-free load phase as the
+// streaming kernel (fully coalesced, ECC in registers); each thread then adds
+// the staged products of its rows, in element order, onto its running sums.
+template <int MODE, int EPT, bool FUSE>
+__global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, CsrPanels P,
+                                                                     const double *__restrict__ x,
+                                                                     double *__restrict__ y, EventRing ev,
+                                                                     FuseOut fuse) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
+  double dsum = 0.0;
+  for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x) {
+    const uint32_t row0 = g * ABFT_PANEL_ROWS;
+    double acc[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) acc[j] = 0.0;
+    for (uint32_t c = 0; c < P.npanels; c++) {
+      const uint32_t seg = g * P.npanels + c;
+      const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+      if (e0 == e1) continue;  // uniform
+      const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+      uint32_t rs[RPT], re[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {  // this thread's rows: row0 + j*256 + tid
+        const uint32_t r = (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+        rs[j] = e0 + ptr[r];
+        re[j] = e0 + ptr[r + 1];
+      }
+      for (uint32_t lo = e0; lo < e1;) {
+        const uint32_t b = lo & ~1u;
+        const uint32_t hi = min(e1, b + TILE);
+        __syncthreads();
+        csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+          const uint32_t a0 = max(rs[j], lo), a1 = min(re[j], hi);
+          if (a0 < a1) {
+            double t = acc[j];
+            csr_row_sum<MODE>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
+            acc[j] = t;
+          }
+        }
+        lo = hi;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t row = row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      if (row < A.n_out) {
+        y[row] = acc[j];
+        if (FUSE) dsum += x[row] * acc[j];
+      }
+    }
+  }
+  if (FUSE) fused_dot_finish(dsum, fuse);
+}
+
+template <int MODE>
+static hipError_t launch_panels_mode(const CsrDev &A, const CsrPanels &P, const double *x, double *y,
+                                     EventRing ev, const FuseOut *fuse, uint32_t grid, hipStream_t s) {
+  if (fuse)
+    hipLaunchKernelGGL((spmv_csr_panels_kernel<MODE, ABFT_CFG_PANEL_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0,
+                       s, A, P, x, y, ev, *fuse);
+  else
+    hipLaunchKernelGGL((spmv_csr_panels_kernel<MODE, ABFT_CFG_PANEL_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0,
+                       s, A, P, x, y, ev, FuseOut{});
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, hipStream_t s) {
+  if (P.ngroups == 0) return hipSuccess;
+  switch (mode) {
+    case MODE_NONE: return launch_panels_mode<MODE_NONE>(A, P, x, y, ev, fuse, grid, s);
+    case MODE_SED: return launch_panels_mode<MODE_SED>(A, P, x, y, ev, fuse, grid, s);
+    case MODE_SEC7: return launch_panels_mode<MODE_SEC7>(A, P, x, y, ev, fuse, grid, s);
+    case MODE_SEC8: return launch_panels_mode<MODE_SEC8>(A, P, x, y, ev, fuse, grid, s);
+    case MODE_SECDED: return launch_panels_mode<MODE_SECDED>(A, P, x, y, ev, fuse, grid, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int MODE, bool FUSE> static int panels_occupancy() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_csr_panels_kernel<MODE, ABFT_CFG_PANEL_EPT, FUSE>,
+                                                   ABFT_BLOCK, 0) != hipSuccess || n < 1)
+    n = 1;
+  return n > 8 ? 8 : n;
+}
+
+int spmv_csr_panels_blocks_per_cu(int mode, bool fuse) {
+  switch (mode) {
+    case MODE_NONE: return fuse ? panels_occupancy<MODE_NONE, true>() : panels_occupancy<MODE_NONE, false>();
+    case MODE_SED: return fuse ? panels_occupancy<MODE_SED, true>() : panels_occupancy<MODE_SED, false>();
+    case MODE_SEC7: return fuse ? panels_occupancy<MODE_SEC7, true>() : panels_occupancy<MODE_SEC7, false>();
+    case MODE_SEC8: return fuse ? panels_occupancy<MODE_SEC8, true>() : panels_occupancy<MODE_SEC8, false>();
+    default: return fuse ? panels_occupancy<MODE_SECDED, true>() : panels_occupancy<MODE_SECDED, false>();
+  }
+}
+
 template <int MODE>
 static hipError_t launch_spmv_csr_mode(const CsrDev &A, const double *x, double *y, EventRing ev,
                                        const FuseOut *fuse, hipStream_t s) {
@@ -484,7 +604,7 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const bool in = ok[s] && row[s] < A.n_in;
-    xv[s] = x[in ? row[s] : 0u];
+    xv[s] = gather_load(x + (in ? row[s] : 0u));
     xv[s] = in ? xv[s] : 0.0;
   }
 #pragma unroll
@@ -597,8 +717,10 @@ hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y
 
 // The XOR half of inject_bitflip (reference CSR/CPUContext.cpp:146-158); the
 // rand() draws stay on the host.
-__global__ void inject_csr_kernel(double *vals, uint32_t *cols, uint32_t index, const int *bits, int nbits) {
+__global__ void inject_csr_kernel(double *vals, uint32_t *cols, const uint32_t *pos_of_orig, uint32_t index,
+                                  const int *bits, int nbits) {
   if (blockIdx.x || threadIdx.x) return;
+  if (pos_of_orig) index = pos_of_orig[index];  // panel layout: caller's index -> storage position
   uint32_t *vw = reinterpret_cast<uint32_t *>(vals + index);
   for (int k = 0; k < nbits; k++) {
     const int bit = bits[k];
@@ -615,9 +737,9 @@ __global__ void inject_coo_kernel(uint4 *elems, const uint32_t *pos_of_orig, uin
   for (int k = 0; k < nbits; k++) w[bits[k] >> 5] ^= 1u << (bits[k] & 31);
 }
 
-hipError_t launch_inject_csr(double *vals, uint32_t *cols, uint32_t index, const int *bits_dev,
-                             int nbits, hipStream_t s) {
-  hipLaunchKernelGGL(inject_csr_kernel, dim3(1), dim3(64), 0, s, vals, cols, index, bits_dev, nbits);
+hipError_t launch_inject_csr(double *vals, uint32_t *cols, const uint32_t *pos_of_orig, uint32_t index,
+                             const int *bits_dev, int nbits, hipStream_t s) {
+  hipLaunchKernelGGL(inject_csr_kernel, dim3(1), dim3(64), 0, s, vals, cols, pos_of_orig, index, bits_dev, nbits);
   return hipGetLastError();
 }
 hipError_t launch_inject_coo(uint4 *elems, const uint32_t *pos_of_orig, uint32_t index,

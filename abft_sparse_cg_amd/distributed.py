@@ -49,8 +49,15 @@ class HipEngine:
         torch.cuda.set_device(device)
         self.pending = []
         self.ctx = HIPContext(mode, fmt, device=device, on_event=lambda ev, fatal: self.pending.extend(ev))
-        # run the kernels on torch's current stream so collectives and kernels are ordered
-        capi.check(self.ctx.L.abft_hip_set_stream(self.ctx.h, torch.cuda.current_stream().cuda_stream))
+        # One stream for everything: make a torch stream this thread's current
+        # stream (torch.distributed enqueues collectives relative to it) and run the
+        # library's kernels on the same stream, so kernels and collectives are
+        # ordered by the stream itself.  (The legacy default stream, handle 0, is
+        # not usable for this: the library reads a null handle as "own stream".)
+        self.tstream = torch.cuda.Stream(device=device)
+        torch.cuda.set_stream(self.tstream)
+        assert self.tstream.cuda_stream != 0
+        capi.check(self.ctx.L.abft_hip_set_stream(self.ctx.h, self.tstream.cuda_stream))
         self.L = self.ctx.L
 
     def create_matrix(self, cols, rows, vals, n_out, n_in, index_base):
@@ -99,7 +106,9 @@ class HipEngine:
         self.ctx.synchronize()
 
     def close(self):
+        torch.cuda.current_stream().synchronize()
         self.ctx.close()
+        torch.cuda.set_stream(torch.cuda.default_stream(self.device))
 
 
 def pad_columns(cols, bounds, slot):
