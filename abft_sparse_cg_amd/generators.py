@@ -26,6 +26,10 @@ def load():
         L.abft_gen_fill.argtypes = [C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.abft_gen_partition.restype = C.c_int
         L.abft_gen_partition.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+        L.abft_glibc_rand_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint]
+        L.abft_load_mtx.restype = C.c_int
+        L.abft_load_mtx.argtypes = [C.c_char_p, C.c_int] + [C.c_void_p] * 6
+        L.abft_free_triplets.argtypes = [C.c_void_p] * 3
         _lib = L
     return _lib
 
@@ -60,3 +64,33 @@ def partition(spec, parts):
     if load().abft_gen_partition(spec.encode(), parts, b.ctypes.data) != 0:
         raise ValueError("bad matrix spec %r" % spec)
     return [int(v) for v in b]
+
+
+def reference_rhs(n, seed=1):
+    """b[i] = rand() / RAND_MAX for glibc's rand() after srand(seed): the right-hand
+    side the reference driver builds (cg.cpp:66-74)."""
+    out = np.empty(n, dtype=np.float64)
+    load().abft_glibc_rand_fill(out.ctypes.data, n, seed)
+    return out
+
+
+def load_mtx(path, num_blocks=1):
+    """Matrix-Market file in the reference loader's dialect (cg.cpp:342-418):
+    -> (cols, rows, vals, N, block_size)."""
+    L = load()
+    n, bs, nnz = C.c_int(), C.c_int(), C.c_int()
+    pc, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = L.abft_load_mtx(path.encode(), num_blocks, C.byref(n), C.byref(bs), C.byref(nnz), C.byref(pc), C.byref(pr),
+                         C.byref(pv))
+    if rc == 1:
+        raise FileNotFoundError(path)
+    if rc == 2:
+        raise ValueError("Matrix is not square")
+    if rc != 0:
+        raise ValueError("Failed to read matrix data")
+    k = nnz.value
+    cols = np.ctypeslib.as_array(C.cast(pc, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
+    rows = np.ctypeslib.as_array(C.cast(pr, C.POINTER(C.c_uint32)), shape=(max(k, 1),))[:k].copy()
+    vals = np.ctypeslib.as_array(C.cast(pv, C.POINTER(C.c_double)), shape=(max(k, 1),))[:k].copy()
+    L.abft_free_triplets(pc, pr, pv)
+    return cols, rows, vals, n.value, bs.value

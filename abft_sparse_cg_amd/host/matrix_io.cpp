@@ -2,6 +2,7 @@
 // 500-line NIST mmio library for one header function (cg.cpp:355 -> mmio.c:192);
 // the dialect it accepts is small enough to state directly.
 #include "matrix_io.h"
+#include "glibc_rand.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -106,4 +107,13 @@ extern "C" void abft_free_triplets(uint32_t *cols, uint32_t *rows, double *vals)
   free(cols);
   free(rows);
   free(vals);
+}
+
+// out[i] = rand() / RAND_MAX for the first n draws after srand(seed): the
+// right-hand side of the reference driver (cg.cpp:66-74), for the Python side
+extern "C" void abft_glibc_rand_fill(double *out, int64_t n, unsigned seed)
+{
+  GlibcRand g(seed);
+  for (int64_t i = 0; i < n; i++)
+    out[i] = g.next() / 2147483647.0;
 }

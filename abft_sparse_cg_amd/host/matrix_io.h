@@ -21,6 +21,8 @@ int abft_load_mtx(const char *path, int num_blocks, int *N, int *block_size, int
                   uint32_t **cols, uint32_t **rows, double **vals);
 void abft_free_triplets(uint32_t *cols, uint32_t *rows, double *vals);
 
+void abft_glibc_rand_fill(double *out, int64_t n, unsigned seed);
+
 // generators.cpp
 int64_t abft_gen_dim(const char *spec);
 int64_t abft_gen_count(const char *spec, int64_t row0, int64_t row1, int64_t *row_nnz);

@@ -9,6 +9,7 @@ import json
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -109,3 +110,32 @@ def test_synthetic_input_and_fixed_iterations():
     assert "number of non-zeros   = 448800 " in out.stdout
     assert "ran for 50 iterations\n" in out.stdout
     assert "iteration " not in out.stdout
+
+
+def run_py(args, sharded=False):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    if sharded:
+        env["ABFT_CG_SHARDED"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), "-m", "abft_sparse_cg_amd.cg"] + args
+    else:
+        cmd = [sys.executable, "-m", "abft_sparse_cg_amd.cg"] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+
+
+@pytest.mark.parametrize("sharded", [False, True])
+def test_python_driver_transcripts_match_reference(sharded):
+    """abft_sparse_cg_amd.cg (single process, and the row-partitioned path with one
+    rank over RCCL) prints what the reference cg-csr prints on the same input."""
+    runs = {tuple(r["args"]): r for r in json.load(open(os.path.join(G, "cli.json"))) if r["fmt"] == "csr"}
+    for args in (["-b", "1", "-m", "none"], ["-b", "4", "-m", "secded"]):
+        out = run_py(["-f", MTX] + args, sharded)
+        assert out.returncode == 0, out.stdout[-800:] + out.stderr[-2000:]
+        text = out.stdout
+        if sharded:  # RCCL prints a version banner on stdout when the communicator is created
+            text = text[text.index("\nimplementation"):]
+        compare_transcripts(text, runs[tuple(args)]["stdout"])
+    out = run_py(["-f", MTX, "-b", "1", "-m", "sed", "--flip-at", "77:3"], sharded)
+    assert out.returncode == 1, out.stdout[-500:] + out.stderr[-1500:]
+    assert out.stdout.rstrip("\n").endswith("[ECC] error detected at index 77")
+    assert "*** flipping bit 3 at index 77 ***" in out.stdout
