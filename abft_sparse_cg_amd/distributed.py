@@ -175,6 +175,7 @@ class ShardedCG:
         self.t_scal = engine.tensor(self.scal)
         engine.upload(self.p_full, np.zeros(self.n_pad))
         self.events = []
+        self._p2p_cache = {}
 
     # ---- collectives -------------------------------------------------------
     def exchange(self, full_vec_tensor):
@@ -185,16 +186,22 @@ class ShardedCG:
         if not self.use_windows:
             dist.all_gather_into_tensor(full_vec_tensor, full_vec_tensor[me * S:(me + 1) * S], group=self.group)
             return
-        ops = []
-        for g in range(self.G):
-            if g == me:
-                continue
-            lo, hi = self.all_need[g][me]  # what peer g reads from my slot
-            if hi > lo:
-                ops.append(dist.P2POp(dist.isend, full_vec_tensor[me * S + lo:me * S + hi], self._peer(g), self.group))
-            lo, hi = self.need[g]
-            if hi > lo:
-                ops.append(dist.P2POp(dist.irecv, full_vec_tensor[g * S + lo:g * S + hi], self._peer(g), self.group))
+        key = full_vec_tensor.data_ptr()
+        ops = self._p2p_cache.get(key)
+        if ops is None:  # the windows are fixed for the life of the solver: build the op list once per buffer
+            ops = []
+            for g in range(self.G):
+                if g == me:
+                    continue
+                lo, hi = self.all_need[g][me]  # what peer g reads from my slot
+                if hi > lo:
+                    ops.append(dist.P2POp(dist.isend, full_vec_tensor[me * S + lo:me * S + hi], self._peer(g),
+                                          self.group))
+                lo, hi = self.need[g]
+                if hi > lo:
+                    ops.append(dist.P2POp(dist.irecv, full_vec_tensor[g * S + lo:g * S + hi], self._peer(g),
+                                          self.group))
+            self._p2p_cache[key] = ops
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

@@ -210,7 +210,7 @@ def main():
             "unit": "CG iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic"}
-    if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+    if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("ABFT_BENCH_SHARDED") != "1":
         dt, n, nnz, roof, kernels, cpu, probe, rr = single(args)
         out = dict(base)
         out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
