@@ -121,11 +121,15 @@ def pad_columns(cols, bounds, slot):
 class ShardedCG:
     """One rank's share of a row-partitioned CG solve."""
 
-    def __init__(self, engine, cols, rows, vals, bounds, nnz_before, mode, group=None, fmt_id=capi.FMT_CSR):
+    def __init__(self, engine, cols, rows, vals, bounds, nnz_before, mode, group=None, fmt_id=capi.FMT_CSR,
+                 staged=False):
         """cols/rows/vals: this rank's rows (global indices, sorted by (row,col));
         bounds: the G+1 row-block boundaries; nnz_before: elements in lower ranks
-        (the global index of this shard's first element)."""
+        (the global index of this shard's first element).  staged=True runs every
+        collective on host copies of the device buffers: for backends that cannot
+        move device memory (gloo), e.g. several ranks sharing one GPU in tests."""
         self.e, self.group, self.mode, self.fmt_id = engine, group, mode, fmt_id
+        self.staged = staged
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         assert len(bounds) == self.G + 1
@@ -183,10 +187,15 @@ class ShardedCG:
         if self.G == 1:
             return
         S, me = self.slot, self.rank
+        if self.staged:
+            dev_tensor, full_vec_tensor = full_vec_tensor, full_vec_tensor.cpu()
         if not self.use_windows:
-            dist.all_gather_into_tensor(full_vec_tensor, full_vec_tensor[me * S:(me + 1) * S], group=self.group)
+            dist.all_gather_into_tensor(full_vec_tensor, full_vec_tensor[me * S:(me + 1) * S].clone()
+                                        if self.staged else full_vec_tensor[me * S:(me + 1) * S], group=self.group)
+            if self.staged:
+                dev_tensor.copy_(full_vec_tensor)
             return
-        key = full_vec_tensor.data_ptr()
+        key = None if self.staged else full_vec_tensor.data_ptr()
         ops = self._p2p_cache.get(key)
         if ops is None:  # the windows are fixed for the life of the solver: build the op list once per buffer
             ops = []
@@ -201,19 +210,23 @@ class ShardedCG:
                 if hi > lo:
                     ops.append(dist.P2POp(dist.irecv, full_vec_tensor[g * S + lo:g * S + hi], self._peer(g),
                                           self.group))
-            self._p2p_cache[key] = ops
+            if key is not None:
+                self._p2p_cache[key] = ops
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if self.staged:
+            dev_tensor.copy_(full_vec_tensor)
 
     def _peer(self, g):
         return dist.get_global_rank(self.group, g) if self.group is not None else g
 
     def _allreduce_scalar(self):
         """-> (sum over ranks, total queued events); synchronises."""
+        t = self.t_scal.cpu() if self.staged else self.t_scal
         if self.G > 1:
-            dist.all_reduce(self.t_scal, op=dist.ReduceOp.SUM, group=self.group)
-        v = self.t_scal.tolist()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        v = t.tolist()
         return v[0], int(v[1])
 
     def _collect_events(self):
@@ -298,7 +311,7 @@ class ShardedCG:
         err = np.abs(self.e.download(self.b) - ax)
         t = torch.tensor([float((err * err).sum()), float(err.max() if len(err) else 0.0)], dtype=torch.float64)
         if self.G > 1:
-            dev = self.t_scal.device
+            dev = "cpu" if self.staged else self.t_scal.device
             s = t[:1].to(dev)
             m = t[1:].to(dev)
             dist.all_reduce(s, op=dist.ReduceOp.SUM, group=self.group)

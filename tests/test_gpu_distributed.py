@@ -1,11 +1,15 @@
 """The sharded solver with the REAL engine (HipEngine -> libabft_hip.so) on the
-one GPU of the test box: world_size 1 over the nccl (RCCL) backend, which
-exercises the device-memory aliasing, the shared stream and the collective calls
-end to end.  Multi-rank logic is covered on CPU by test_distributed_gloo.
+one GPU of the test box.
 
-Each case runs in a child process (tests/_gpu_dist_worker.py) under a timeout:
-RCCL bootstrap inside a long-lived pytest process was seen to stall once, and a
-stall there must cost one test, not the whole run."""
+* world size 1 over the nccl (RCCL) backend: device-memory aliasing, the shared
+  stream and the collective calls end to end;
+* world size 2 and 3 with every rank on the same GPU, gloo backend and host-staged
+  collectives: the multi-rank shard geometry -- padded column layout, halo windows
+  vs all-gather, global event indices, fatal stop on every rank -- with the real
+  kernels (RCCL refuses two ranks on one device, so this is how several HIP shards
+  can be exercised on a one-GPU box).
+The multi-rank collective logic itself is also covered on CPU by
+test_distributed_gloo.  Every rank is a child process under a timeout."""
 import json
 import os
 import socket
@@ -15,13 +19,14 @@ import sys
 import numpy as np
 import pytest
 
-from _oracle import CSR, OracleMatrix, laplace5, rhs
+from _oracle import CSR, OracleMatrix, laplace5, random_spd, rhs
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, "_gpu_dist_worker.py")
 
 
-def run_worker(mode, flip):
+def run_job(backend, world, matrix, mode, flip):
     idx, bit = flip if flip else (-1, 0)
     last = None
     for attempt in range(2):
@@ -29,29 +34,36 @@ def run_worker(mode, flip):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
+        procs = [subprocess.Popen([sys.executable, WORKER, backend, str(r), str(world), matrix, mode, str(idx),
+                                   str(bit), str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                 for r in range(world)]
+        outs = []
         try:
-            p = subprocess.run([sys.executable, os.path.join(HERE, "_gpu_dist_worker.py"), mode, str(idx), str(bit),
-                                str(port)], capture_output=True, text=True, timeout=240)
-        except subprocess.TimeoutExpired as e:
-            last = "timeout: %s" % e
+            for p in procs:
+                outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for p in procs:
+                p.kill()
+            last = "timeout"
             continue
-        lines = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+        lines = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")]
         if lines:
-            return json.loads(lines[-1][7:]), p.stdout
-        last = p.stdout[-2000:] + p.stderr[-2000:]
-    pytest.fail("worker did not finish: %s" % last)
+            return json.loads(lines[-1][7:]), outs[0][0], [p.returncode for p in procs]
+        last = outs[0][0][-1500:] + outs[0][1][-3000:]
+    pytest.fail("job did not finish: %s" % last)
 
 
-@pytest.mark.parametrize("mode,flip", [("none", None), ("secded", (777, 40)), ("sec7", (5, 70))])
-def test_sharded_engine_world1_matches_oracle(mode, flip):
-    cols, rows, vals, n = laplace5(48, 48)
-    b = rhs(n, 1)
+def oracle(matrix, mode, flip):
+    cols, rows, vals, n = laplace5(48, 48) if matrix == "laplace" else random_spd(1500, 10, seed=3)
     o = OracleMatrix(CSR, mode, cols, rows, vals, n)
     if flip:
         o.inject(flip[0], [flip[1]])
-    it_o, hist_o, x_o, _ = o.cg(b)
-    ev_o, _ = o.events()
-    out, stdout = run_worker(mode, flip)
+    it, hist, x, fatal = o.cg(rhs(n, 1))
+    ev, _ = o.events()
+    return it, hist, x, ev, len(vals)
+
+
+def check(out, stdout, it_o, hist_o, x_o, ev_o):
     assert out["exit"] == 0 and out["it"] == it_o
     assert np.allclose(out["hist"], hist_o, rtol=1e-10, atol=0)
     assert np.abs(np.array(out["x"]) - x_o).max() <= 1e-10 * np.abs(x_o).max()
@@ -61,8 +73,35 @@ def test_sharded_engine_world1_matches_oracle(mode, flip):
         assert stdout.count("at index %d\n" % i) == 1
 
 
-def test_sed_fatal_exits_with_status_1():
-    out, stdout = run_worker("sed", (99, 3))
+@pytest.mark.parametrize("mode,flip", [("none", None), ("secded", (777, 40)), ("sec7", (5, 70))])
+def test_world1_over_rccl_matches_oracle(mode, flip):
+    it_o, hist_o, x_o, ev_o, _ = oracle("laplace", mode, flip)
+    out, stdout, codes = run_job("nccl", 1, "laplace", mode, flip)
+    check(out, stdout, it_o, hist_o, x_o, ev_o)
+
+
+def test_world1_sed_fatal_exits_with_status_1():
+    out, stdout, codes = run_job("nccl", 1, "laplace", "sed", (99, 3))
     assert out["exit"] == 1
     assert [tuple(e) for e in out["events"]] == [(1, 99, 0)]
     assert "[ECC] error detected at index 99\n" in stdout
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("matrix", ["laplace", "random"])
+def test_several_hip_shards_on_one_gpu(world, matrix):
+    """real kernels, real shard geometry; a flip in the LAST rank's shard"""
+    nnz = oracle(matrix, "none", None)[4]
+    flip = (nnz - 40, 21)
+    it_o, hist_o, x_o, ev_o, _ = oracle(matrix, "secded", flip)
+    out, stdout, codes = run_job("gloo", world, matrix, "secded", flip)
+    assert codes == [0] * world
+    check(out, stdout, it_o, hist_o, x_o, ev_o)
+    assert ev_o == [(2, nnz - 40, 21)]
+    assert out["windows"] == (matrix == "laplace")
+
+
+def test_fatal_event_on_one_shard_stops_every_rank():
+    out, stdout, codes = run_job("gloo", 2, "laplace", "sed", (7, 70))
+    assert out["exit"] == 1 and [tuple(e) for e in out["events"]] == [(1, 7, 0)]
+    assert "[ECC] error detected at index 7\n" in stdout
