@@ -488,7 +488,7 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
     const int per_cu = spmv_csr_panels_blocks_per_cu(mode, true);
     m->panel_grid = std::min<uint32_t>(m->panels.ngroups, (uint32_t)(per_cu * ctx->num_cus));
   }
-  if (n_out == n_in && nblk > 0) {  // square: spmv can also deliver vec.result
+  if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
     if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(nblk, 4096) * sizeof(double)) != hipSuccess) {
       matrix_free(m);
       *out = nullptr;
@@ -739,13 +739,14 @@ extern "C" int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, con
 }
 
 static int calc_xr_launch(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r, const abft_hip_vector *p,
-                          const abft_hip_vector *w, double alpha, const ReduceOut &o) {
+                          const abft_hip_vector *w, double alpha, const ReduceOut &o,
+                          const double *num = nullptr, const double *den = nullptr) {
   if (int rc = check_same(x, r, "calc_xr")) return rc;
   if (int rc = check_same(x, p, "calc_xr")) return rc;
   if (int rc = check_same(x, w, "calc_xr")) return rc;
   ctx->fused.valid = false;
   KernelTimer t(ctx, ABFT_K_CALC_XR);
-  HIPCHK(launch_calc_xr(x->d, r->d, p->d, w->d, alpha, x->n, o, ctx->stream));
+  HIPCHK(launch_calc_xr(x->d, r->d, p->d, w->d, alpha, num, den, x->n, o, ctx->stream));
   return ABFT_OK;
 }
 
@@ -771,12 +772,35 @@ extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft
   if (int rc = check_same(p, r, "calc_p")) return rc;
   ctx->fused.valid = false;
   KernelTimer t(ctx, ABFT_K_CALC_P);
-  HIPCHK(launch_calc_p(p->d, r->d, beta, p->n, ctx->stream));
+  HIPCHK(launch_calc_p(p->d, r->d, beta, nullptr, nullptr, p->n, ctx->stream));
   return ABFT_OK;
 }
 
-extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
-                             abft_hip_vector *result) {
+// ---- device-scalar forms: alpha and beta never leave the GPU -------------------
+
+extern "C" int abft_hip_calc_xr_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
+                                          const abft_hip_vector *p, const abft_hip_vector *w,
+                                          const double *dev_num, const double *dev_den, double *dev_result) {
+  if (int rc = bind(ctx)) return rc;
+  if (!dev_num || !dev_den || !dev_result) return set_err(ABFT_ERR_INVALID, "null device scalar");
+  return calc_xr_launch(ctx, x, r, p, w, 0.0, reduce_out(ctx, dev_result, false), dev_num, dev_den);
+}
+
+extern "C" int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r,
+                                         const double *dev_num, const double *dev_den) {
+  if (int rc = bind(ctx)) return rc;
+  if (int rc = check_same(p, r, "calc_p")) return rc;
+  if (!dev_num || !dev_den) return set_err(ABFT_ERR_INVALID, "null device scalar");
+  ctx->fused.valid = false;
+  KernelTimer t(ctx, ABFT_K_CALC_P);
+  HIPCHK(launch_calc_p(p->d, r->d, 0.0, dev_num, dev_den, p->n, ctx->stream));
+  return ABFT_OK;
+}
+
+// Shared by abft_hip_spmv (dev_pair == nullptr: the fused product, if any, goes to
+// the pinned slot for a following dot) and abft_hip_spmv_dot_dev.
+static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                       abft_hip_vector *result, int vec_offset, double *dev_pair) {
   if (int rc = bind(ctx)) return rc;
   if (!mat || !vec || !result) return set_err(ABFT_ERR_INVALID, "spmv: null argument");
   const uint32_t n_out = mat->fmt == ABFT_FMT_CSR ? mat->csr.n_out : mat->coo.n_out;
@@ -786,15 +810,22 @@ extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft
     return set_err(ABFT_ERR_INVALID, "spmv: vectors (%d in, %d out) shorter than the matrix (%u in, %u out)",
                    vec->n, result->n, n_in, n_out);
   if (vec->d == result->d) return set_err(ABFT_ERR_INVALID, "spmv: input and output alias");
+  if (dev_pair && (vec_offset < 0 || (uint64_t)vec_offset + n_out > (uint64_t)vec->n))
+    return set_err(ABFT_ERR_INVALID, "spmv_dot: window [%d,%llu) outside the input vector of %d", vec_offset,
+                   (unsigned long long)vec_offset + n_out, vec->n);
   ctx->fused.valid = false;
   FuseOut fuse{};
-  const bool do_fuse = ctx->fuse_enabled && mat->fuse_partials && n_in == n_out &&
-                       (uint32_t)vec->n == n_in && (uint32_t)result->n == n_out;
+  const bool to_host = !dev_pair && ctx->fuse_enabled && n_in == n_out && (uint32_t)vec->n == n_in &&
+                       (uint32_t)result->n == n_out;
+  const bool do_fuse = mat->fuse_partials && (dev_pair || to_host);
+  if (dev_pair && !do_fuse) return set_err(ABFT_ERR_INVALID, "spmv_dot: matrix has no rows");
   if (do_fuse) {
     fuse.partials = mat->fuse_partials;
-    fuse.host = ctx->host_slot_dev;
+    fuse.host = dev_pair ? nullptr : ctx->host_slot_dev;
+    fuse.dev_out = dev_pair;
     fuse.ev_count = ctx->ring.count;
-    fuse.seq = ++ctx->seq;
+    fuse.seq = dev_pair ? 0 : ++ctx->seq;
+    fuse.x_off = dev_pair ? (uint32_t)vec_offset : 0u;
   }
   uint32_t nparts = mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk;
   {
@@ -812,7 +843,7 @@ extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
     HIPCHK(launch_fuse_finalize(fuse, nparts, ctx->stream));
   }
-  if (do_fuse) {
+  if (to_host && do_fuse) {
     ctx->fused.valid = true;
     ctx->fused.have_value = false;
     ctx->fused.x = vec->d;
@@ -821,6 +852,17 @@ extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft
     ctx->fused.seq = fuse.seq;
   }
   return ABFT_OK;
+}
+
+extern "C" int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                             abft_hip_vector *result) {
+  return spmv_common(ctx, mat, vec, result, 0, nullptr);
+}
+
+extern "C" int abft_hip_spmv_dot_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                                     abft_hip_vector *result, int vec_offset, double *dev_result) {
+  if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
+  return spmv_common(ctx, mat, vec, result, vec_offset, dev_result);
 }
 
 // ------------------------------------------------------------------- events --

@@ -123,10 +123,12 @@ struct ReduceOut {
 // partial; a one-block kernel behind the SpMV folds them in a fixed order and
 // publishes the scalar like a reduction does.  `partials` belongs to the matrix.
 struct FuseOut {
-  double *partials;  // nblk
-  HostSlot *host;
+  double *partials;  // one per SpMV workgroup
+  HostSlot *host;    // publish to the pinned slot (host-scalar form) ...
+  double *dev_out;   // ... or {sum, queued events} to device memory (device-scalar form)
   const uint32_t *ev_count;
   uint32_t seq;
+  uint32_t x_off;    // the product uses vec[x_off + row] (a shard's slot in the gathered vector)
 };
 
 // panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
@@ -142,8 +144,10 @@ hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y
 
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);
+// alpha = num ? *num / *den : alpha (device-resident scalars: no host round trip)
 hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w, double alpha,
-                          int n, const ReduceOut &out, hipStream_t s);
-hipError_t launch_calc_p(double *p, const double *r, double beta, int n, hipStream_t s);
+                          const double *num, const double *den, int n, const ReduceOut &out, hipStream_t s);
+hipError_t launch_calc_p(double *p, const double *r, double beta, const double *num, const double *den, int n,
+                         hipStream_t s);
 hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s);
 hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s);

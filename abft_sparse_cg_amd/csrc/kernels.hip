@@ -214,10 +214,16 @@ __global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t
     double tot = 0.0;
     for (int k = 0; k < 16; k++) tot += s_w[k];
     const uint32_t nev = *f.ev_count;
-    __hip_atomic_store(&f.host->value, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&f.host->evcount, nev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&f.host->seq, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (f.dev_out) {
+      f.dev_out[0] = tot;
+      f.dev_out[1] = (double)nev;
+    }
+    if (f.host) {
+      __hip_atomic_store(&f.host->value, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&f.host->evcount, nev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&f.host->seq, f.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -369,14 +375,14 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
     double xr = 0.0;
     if (r < row1) {
       rs = A.rowptr[r]; re = A.rowptr[r + 1];
-      if (FUSE) xr = x[r];
+      if (FUSE) xr = x[fuse.x_off + r];
     }
     csr_stage<MODE, EPT>(A, x, ev, base, e0, e1, s_prod, s_col);
     __syncthreads();
     for (uint32_t row = r; row < row1; row += ABFT_BLOCK) {
       if (row != r) {
         rs = A.rowptr[row]; re = A.rowptr[row + 1];
-        if (FUSE) xr = x[row];
+        if (FUSE) xr = x[fuse.x_off + row];
       }
       if (MODE == MODE_CONSTRAINTS) {  // reference CSR/CPUContext.cpp:173-182
         if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
       }
       if (threadIdx.x == 0 && ok) {
         y[row] = acc;
-        if (FUSE) dsum += x[row] * acc;
+        if (FUSE) dsum += x[fuse.x_off + row] * acc;
       }
     }
   }
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
       const uint32_t row = row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
       if (row < A.n_out) {
         y[row] = acc[j];
-        if (FUSE) dsum += x[row] * acc[j];
+        if (FUSE) dsum += x[fuse.x_off + row] * acc[j];
       }
     }
   }
@@ -651,14 +657,14 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
     double xg = 0.0;
     if (g < g1) {
       gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1];
-      if (FUSE) xg = x[g];
+      if (FUSE) xg = x[fuse.x_off + g];
     }
     coo_stage<MODE, EPT>(A, x, ev, e0, e1, s_prod);
     __syncthreads();
     for (uint32_t grp = g; grp < g1; grp += ABFT_BLOCK) {
       if (grp != g) {
         gs = A.grp_ptr[grp]; ge = A.grp_ptr[grp + 1];
-        if (FUSE) xg = x[grp];
+        if (FUSE) xg = x[fuse.x_off + grp];
       }
       // reference zero-fills result first (COO/CPUContext.cpp:108-109)
       const double acc = lds_ordered_sum(s_prod, gs - e0, ge - e0);
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
       }
       if (threadIdx.x == 0) {
         y[grp] = acc;
-        if (FUSE) dsum += x[grp] * acc;
+        if (FUSE) dsum += x[fuse.x_off + grp] * acc;
       }
     }
   }
@@ -841,8 +847,10 @@ template <int VEC>
 __global__ __launch_bounds__(ABFT_BLOCK) void calc_xr_kernel(double *__restrict__ x, double *__restrict__ r,
                                                              const double *__restrict__ p,
                                                              const double *__restrict__ w, double alpha,
-                                                             int n, ReduceOut out) {
+                                                             const double *num, const double *den, int n,
+                                                             ReduceOut out) {
   __shared__ double s_w[4];
+  if (num) alpha = *num / *den;  // alpha = rr / pw formed on the device (cg.cpp:102)
   double acc = 0.0;
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
   for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
@@ -872,7 +880,9 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_xr_kernel(double *__restrict_
 // calc_p (reference CSR/CPUContext.cpp:107-113): p = r + beta p
 template <int VEC>
 __global__ __launch_bounds__(ABFT_BLOCK) void calc_p_kernel(double *__restrict__ p, const double *__restrict__ r,
-                                                            double beta, int n) {
+                                                            double beta, const double *num, const double *den,
+                                                            int n) {
+  if (num) beta = *num / *den;  // beta = rr_new / rr formed on the device (cg.cpp:109)
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
   for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
     if (VEC == 2 && i + 1 < n) {
@@ -901,23 +911,24 @@ hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &
   return hipGetLastError();
 }
 
-hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w, double alpha, int n,
-                          const ReduceOut &out, hipStream_t s) {
+hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w, double alpha,
+                          const double *num, const double *den, int n, const ReduceOut &out, hipStream_t s) {
   const int nb = reduce_blocks(n);
   if (aligned16(x, r, p, w))
-    hipLaunchKernelGGL(calc_xr_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, out);
+    hipLaunchKernelGGL(calc_xr_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, num, den, n, out);
   else
-    hipLaunchKernelGGL(calc_xr_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, n, out);
+    hipLaunchKernelGGL(calc_xr_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, r, p, w, alpha, num, den, n, out);
   return hipGetLastError();
 }
 
-hipError_t launch_calc_p(double *p, const double *r, double beta, int n, hipStream_t s) {
+hipError_t launch_calc_p(double *p, const double *r, double beta, const double *num, const double *den, int n,
+                         hipStream_t s) {
   if (n <= 0) return hipSuccess;
   const int nb = reduce_blocks(n);
   if (aligned16(p, r))
-    hipLaunchKernelGGL(calc_p_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, beta, n);
+    hipLaunchKernelGGL(calc_p_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, beta, num, den, n);
   else
-    hipLaunchKernelGGL(calc_p_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, beta, n);
+    hipLaunchKernelGGL(calc_p_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, beta, num, den, n);
   return hipGetLastError();
 }
 

@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--profile-all", action="store_true",
                     help="bracket all four kernels, not only the SpMV (costs ~10%% of the iteration rate)")
+    ap.add_argument("--host-scalars", action="store_true",
+                    help="N > 1: return both scalars to the host every iteration (default: device-resident)")
     ap.add_argument("--probe", action="store_true", help="also measure the streaming-copy bandwidth of the device")
     return ap.parse_args()
 
@@ -168,17 +170,28 @@ def sharded(args):
     eng = HipEngine(args.mode, "csr", device=local)
     cg = ShardedCG(eng, cols, rows, vals, bounds, sum(counts[:rank]), args.mode)
     del cols, rows, vals
-    cg.set_rhs(np.random.default_rng(1).random(n)[r0:r1])
-    cg.start()
-    for _ in range(args.warmup):
-        cg.step()
+    b_local = np.random.default_rng(1).random(n)[r0:r1]
+    cg.set_rhs(b_local)
+    # -c 0 run: alpha and beta stay on the device (ShardedCG.run_fixed), so an
+    # iteration is enqueue-only; --host-scalars times the loop that returns both
+    # scalars to the host every iteration (ShardedCG.step) instead
+    if args.host_scalars:
+        cg.start()
+        for _ in range(args.warmup):
+            cg.step()
+    else:
+        cg.run_fixed(args.warmup)
+        cg.set_rhs(b_local)
     if not args.no_profile:
         eng.ctx.profile(1 << capi.K_SPMV)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        cg.step()
+    if args.host_scalars:
+        for _ in range(args.steps):
+            cg.step()
+    else:
+        cg.run_fixed(args.steps)
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
@@ -229,8 +242,9 @@ def main():
         out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
                     "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec), "N": n,
                                "nnz": nnz, "format": "csr", "mode": args.mode,
-                               "parallelism": "row-block x%d, %s exchange + 2 all-reduce / iteration"
-                                              % (args.gpus, exchange),
+                               "parallelism": "row-block x%d, %s exchange + 2 all-reduce / iteration, scalars %s"
+                                              % (args.gpus, exchange,
+                                                 "returned to the host" if args.host_scalars else "device-resident"),
                                "rr_after_last_step": rr},
                     "roofline": roof, "cpu_baseline": None, "kernels": kernels})
         print(json.dumps(out))

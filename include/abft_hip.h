@@ -175,6 +175,22 @@ int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector 
                          const abft_hip_vector *p, const abft_hip_vector *w, double alpha,
                          double *dev_result);
 
+/* Device-scalar forms, for loops that keep alpha and beta on the device (no host
+ * round trip per iteration; the row-partitioned solver's fixed-iteration loop):
+ *   spmv_dot_dev        result = A vec, and dev_result = {sum_row vec[vec_offset+row]
+ *                       * result[row], queued events}  (vec_offset: the shard's slot
+ *                       in the gathered vector; 0 on one GPU)
+ *   calc_xr_ratio_dev   calc_xr with alpha = *dev_num / *dev_den  (cg.cpp:102)
+ *   calc_p_ratio_dev    calc_p  with beta  = *dev_num / *dev_den  (cg.cpp:109)
+ * All three are asynchronous; every pointer is device memory. */
+int abft_hip_spmv_dot_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                          abft_hip_vector *result, int vec_offset, double *dev_result);
+int abft_hip_calc_xr_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
+                               const abft_hip_vector *p, const abft_hip_vector *w,
+                               const double *dev_num, const double *dev_den, double *dev_result);
+int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r,
+                              const double *dev_num, const double *dev_den);
+
 /* ---- events ------------------------------------------------------------ */
 
 /* Synchronise, then move the queued events to `buf` (at most `cap`), sorted

@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 def main():
     backend, rank, world, matrix, mode, flip_index, flip_bit, port = sys.argv[1:9]
+    fixed = int(sys.argv[9]) if len(sys.argv) > 9 else 0
     rank, world, flip_index, flip_bit = int(rank), int(world), int(flip_index), int(flip_bit)
     import torch
     import torch.distributed as dist
@@ -46,7 +47,10 @@ def main():
     hist = []
     out = {"exit": 0, "windows": bool(cg.use_windows)}
     try:
-        it, rr = cg.solve(on_iteration=lambda i, r: hist.append(r))
+        if fixed:
+            it, hist = fixed, [cg.run_fixed(fixed)]
+        else:
+            it, rr = cg.solve(on_iteration=lambda i, r: hist.append(r))
         x = cg.gather_x()
         tot, mx = cg.residual_check()
         out.update(it=it, hist=hist, x=[float(v) for v in x], tot=tot, mx=mx)

@@ -77,6 +77,18 @@ class OracleEngine:
     def calc_p(self, p, r, beta):
         self.L.ora_calc_p(_p(p.a, f64p), _p(r.a, f64p), beta, p.N)
 
+    def spmv_dot(self, A, x, x_off, y, out):
+        self.spmv(A, x, y)
+        xs = np.ascontiguousarray(x.a[x_off:x_off + y.N])
+        out.a[0] = self.L.ora_dot(_p(xs, f64p), _p(y.a, f64p), y.N)
+        out.a[1] = self._peek()
+
+    def calc_xr_ratio(self, x, r, p, w, num, den, out):
+        self.calc_xr_partial(x, r, p, w, num.a[0] / den.a[0], out)
+
+    def calc_p_ratio(self, p, r, num, den):
+        self.calc_p(p, r, num.a[0] / den.a[0])
+
     def inject(self, A, index, bits):
         A.inject(index, bits)
 
@@ -112,7 +124,8 @@ def _worker(rank, world, port, case, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from abft_sparse_cg_amd.distributed import ShardedCG
-        cols, rows, vals, n, bounds, mode, flip = case
+        cols, rows, vals, n, bounds, mode, flip = case[:7]
+        fixed = case[7] if len(case) > 7 else 0
         r0, r1 = bounds[rank], bounds[rank + 1]
         m = (rows >= r0) & (rows < r1)
         nnz_before = int(np.argmax(m)) if m.any() else 0
@@ -126,8 +139,14 @@ def _worker(rank, world, port, case, q):
                 eng.inject(cg.A, gi - nnz_before, bits)
         hist = []
         code = 0
+        if isinstance(mode, str) and mode.startswith("fixed:"):
+            pass
         try:
-            it, rr = cg.solve(on_iteration=lambda i, r: hist.append(r))
+            if fixed:
+                rr = cg.run_fixed(fixed)
+                it, hist = fixed, [rr]
+            else:
+                it, rr = cg.solve(on_iteration=lambda i, r: hist.append(r))
             x = cg.gather_x()
             tot, mx = cg.residual_check()
         except SystemExit as e:
@@ -216,3 +235,19 @@ def test_pad_columns_layout():
     p, owner = pad_columns(np.array([0, 2, 3, 9, 10, 11], dtype=np.uint32), bounds, 7)
     assert list(owner) == [0, 0, 1, 1, 2, 2]
     assert list(p) == [0, 2, 7, 13, 14, 15]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_fixed_iteration_loop_with_device_scalars(world):
+    """run_fixed (alpha, beta formed on the device, nothing read back per iteration)
+    walks the same iterates as the reference loop."""
+    cols, rows, vals, n = random_spd(300, 8, seed=3)
+    bounds = uneven_bounds(rows, n, world)
+    iters = 12
+    o = OracleMatrix(CSR, "none", cols, rows, vals, n)
+    it_s, hist_s, x_s, _ = o.cg(rhs(n, 1), max_itrs=iters, conv=0.0)
+    assert it_s == iters
+    code, it, hist, x, tot, mx, events, _ = run_case(world, (cols, rows, vals, n, bounds, "none", None, iters))
+    assert code == 0 and it == iters
+    assert abs(hist[-1] - hist_s[-1]) <= 1e-10 * hist_s[-1]
+    assert np.abs(x - x_s).max() <= 1e-10 * np.abs(x_s).max()

@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "_gpu_dist_worker.py")
 
 
-def run_job(backend, world, matrix, mode, flip):
+def run_job(backend, world, matrix, mode, flip, fixed=0):
     idx, bit = flip if flip else (-1, 0)
     last = None
     for attempt in range(2):
@@ -35,7 +35,7 @@ def run_job(backend, world, matrix, mode, flip):
         port = s.getsockname()[1]
         s.close()
         procs = [subprocess.Popen([sys.executable, WORKER, backend, str(r), str(world), matrix, mode, str(idx),
-                                   str(bit), str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                   str(bit), str(port), str(fixed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
                  for r in range(world)]
         outs = []
         try:
@@ -105,3 +105,21 @@ def test_fatal_event_on_one_shard_stops_every_rank():
     out, stdout, codes = run_job("gloo", 2, "laplace", "sed", (7, 70))
     assert out["exit"] == 1 and [tuple(e) for e in out["events"]] == [(1, 7, 0)]
     assert "[ECC] error detected at index 7\n" in stdout
+
+
+@pytest.mark.parametrize("backend,world", [("nccl", 1), ("gloo", 2)])
+@pytest.mark.parametrize("matrix", ["laplace", "random"])
+def test_fixed_iteration_loop_with_device_scalars(backend, world, matrix):
+    """run_fixed: spmv+dot, calc_xr and calc_p take alpha / beta from device memory;
+    after 15 iterations rr and x equal the reference loop's (and the one corrected
+    flip is reported, once, when the loop ends)."""
+    cols, rows, vals, n = laplace5(48, 48) if matrix == "laplace" else random_spd(1500, 10, seed=3)
+    flip = (len(vals) - 40, 21)
+    o = OracleMatrix(CSR, "secded", cols, rows, vals, n)
+    o.inject(flip[0], [flip[1]])
+    it_o, hist_o, x_o, _ = o.cg(rhs(n, 1), max_itrs=15, conv=0.0)
+    out, stdout, codes = run_job(backend, world, matrix, "secded", flip, fixed=15)
+    assert codes == [0] * world and out["exit"] == 0 and out["it"] == it_o == 15
+    assert abs(out["hist"][-1] - hist_o[-1]) <= 1e-10 * hist_o[-1]
+    assert np.abs(np.array(out["x"]) - x_o).max() <= 1e-10 * np.abs(x_o).max()
+    assert [tuple(e) for e in out["events"]] == [(2, flip[0], flip[1])]
