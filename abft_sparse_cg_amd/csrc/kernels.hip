@@ -244,20 +244,38 @@ hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s) 
 // per-element `if`s hipcc puts an s_waitcnt vmcnt(0) at every join and the four
 // gathers of a thread run one after the other.  The only branch left is the
 // ECC cold path, taken when an element fails its check.
-template <int MODE, int EPT>
-__device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restrict__ x,
-                                          const EventRing &ev, uint32_t base, uint32_t lo,
-                                          uint32_t hi, double *s_prod, uint32_t *s_col) {
-  constexpr int STEPS = EPT / 2;
-  f64x2 v[STEPS];
-  u32x2 c[STEPS];
+template <int EPT> struct CsrTileRegs {
+  f64x2 v[EPT / 2];
+  u32x2 c[EPT / 2];
+};
+
+// the streaming loads of one tile: no branches, out-of-tile lanes re-read the first pair
+template <int EPT>
+__device__ __forceinline__ void csr_issue_loads(const CsrDev &A, uint32_t base, uint32_t hi,
+                                                CsrTileRegs<EPT> &t) {
 #pragma unroll
-  for (int s = 0; s < STEPS; s++) {
+  for (int s = 0; s < EPT / 2; s++) {
     const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
     const uint32_t ii = i < hi ? i : base;  // always a valid, even element index
-    v[s] = STREAM_LOAD(reinterpret_cast<const f64x2 *>(A.vals + ii));
-    c[s] = STREAM_LOAD(reinterpret_cast<const u32x2 *>(A.cols + ii));
+    t.v[s] = STREAM_LOAD(reinterpret_cast<const f64x2 *>(A.vals + ii));
+    t.c[s] = STREAM_LOAD(reinterpret_cast<const u32x2 *>(A.cols + ii));
   }
+}
+
+// ECC check, gathers, products -> LDS for a tile whose loads were issued into
+// `t`.  If `prefetch`, the NEXT tile's streaming loads are issued right after
+// this tile's gathers (so the gathers stay older in the memory queue and can be
+// waited for without draining the prefetch).  A persistent, software-pipelined
+// kernel built on this was measured and dropped: 180 us vs 151 us for one tile
+// per workgroup (config 2) -- 8 resident workgroups per CU already overlap each
+// other's phases, and the extra registers cost occupancy.
+template <int MODE, int EPT>
+__device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__restrict__ x,
+                                            const EventRing &ev, uint32_t base, uint32_t lo,
+                                            uint32_t hi, const CsrTileRegs<EPT> &t, double *s_prod,
+                                            uint32_t *s_col, bool prefetch, uint32_t nbase, uint32_t nhi,
+                                            CsrTileRegs<EPT> &nxt) {
+  constexpr int STEPS = EPT / 2;
   uint32_t col[EPT];
   double val[EPT];
   bool ok[EPT];
@@ -265,8 +283,8 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
   for (int j = 0; j < EPT; j++) {
     const int s = j >> 1;
     const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK) + (uint32_t)(j & 1);
-    const double d = (j & 1) ? v[s].y : v[s].x;
-    uint32_t w[3] = {(uint32_t)__double2loint(d), (uint32_t)__double2hiint(d), (j & 1) ? c[s].y : c[s].x};
+    const double d = (j & 1) ? t.v[s].y : t.v[s].x;
+    uint32_t w[3] = {(uint32_t)__double2loint(d), (uint32_t)__double2hiint(d), (j & 1) ? t.c[s].y : t.c[s].x};
     bool valid = i >= lo && i < hi;
     if (MODE >= MODE_SED) {
       if (__builtin_expect(valid && ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
@@ -292,8 +310,13 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
   for (int j = 0; j < EPT; j++) {
     const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
     xv[j] = gather_load(x + (in ? col[j] : 0u));
-    xv[j] = in ? xv[j] : 0.0;
+    ok[j] = in ? ok[j] : ok[j];
+    if (!in) xv[j] = 0.0;
   }
+  // no branch around the prefetch: with one, hipcc drains the whole memory queue
+  // (vmcnt(0)) at the join and the overlap is gone; a caller with nothing to
+  // prefetch passes nhi == nbase, which makes every lane re-read one resident pair
+  if (prefetch) csr_issue_loads<EPT>(A, nbase, nhi, nxt);
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
     const uint32_t k = 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
@@ -302,6 +325,16 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
     if (MODE == MODE_CONSTRAINTS)
       *reinterpret_cast<uint2 *>(s_col + k) = make_uint2(col[2 * s], col[2 * s + 1]);
   }
+}
+
+// load + consume of one tile (the non-pipelined form)
+template <int MODE, int EPT>
+__device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restrict__ x,
+                                          const EventRing &ev, uint32_t base, uint32_t lo,
+                                          uint32_t hi, double *s_prod, uint32_t *s_col) {
+  CsrTileRegs<EPT> t, unused;
+  csr_issue_loads<EPT>(A, base, hi, t);
+  csr_consume<MODE, EPT>(A, x, ev, base, lo, hi, t, s_prod, s_col, false, 0u, 0u, unused);
 }
 
 // Sum one row from the staged products, in ascending element order.  In
