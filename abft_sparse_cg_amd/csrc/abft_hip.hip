@@ -75,9 +75,10 @@ struct abft_hip_matrix {
   CsrDev csr{};
   CooDev coo{};
   double *fuse_partials = nullptr;  // FuseOut buffer (square matrices)
-  bool use_panels = false;          // CSR only: panel layout chosen at create time
+  bool use_panels = false;          // panel layout chosen at create time
   CsrPanels panels{};
-  uint32_t panel_grid = 0;          // persistent workgroups of the panel kernel
+  uint32_t panel_grid = 0;          // workgroups of the panel kernel
+  uint32_t panel_chunk = 0;         // panels per launch (0 = all)
   std::vector<void *> allocs;
 };
 
@@ -274,53 +275,63 @@ struct PanelBuild {
 };
 
 // Decide whether the panel layout pays for this matrix and, if so, build it.
-// It pays when the input vector is much larger than an XCD's L2 and a row group
-// reaches into several panels (scattered columns); banded matrices keep the
-// streaming layout, whose x window already lives in L2.  Needs columns ascending
-// within a row (as the reference loader delivers them): panels are swept in
-// ascending order, so the additions of a row then happen in the caller's order.
+// `out_idx` / `in_idx` are the element's output index and gather index (CSR: row /
+// column; COO: column / row).  It pays when the input vector is much larger than
+// an XCD's L2 and an output group reaches into several panels (scattered gather
+// indices); banded matrices keep the streaming layout, whose x window already
+// lives in L2.  Needs the gather indices of one output to be non-decreasing in
+// the caller's order (as the reference loader delivers them): panels are swept
+// in ascending order, so an output's additions then happen in the caller's order.
 // ABFT_HIP_LAYOUT=stream|panels|auto and ABFT_HIP_PANEL_WIDTH (entries) override.
-static bool plan_panels(int mode, const uint32_t *columns, const uint32_t *rows, int n_out, int n_in, int nnz,
+static bool plan_panels(int mode, const uint32_t *in_idx, const uint32_t *out_idx, int n_out, int n_in, int nnz,
                         PanelBuild &pb) {
   const char *env = getenv("ABFT_HIP_LAYOUT");
   const bool force = env && !strcmp(env, "panels");
   if ((env && !strcmp(env, "stream")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0) return false;
-  uint32_t width = 1u << 18;  // 2 MB of x per panel: two panels fit an XCD's 4 MB L2
+  uint32_t width = 1u << 18;  // 2 MB of x per panel; two panels per launch (ABFT_HIP_PANEL_CHUNK)
   if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
   if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
   const uint64_t ngroups = ((uint64_t)n_out + ABFT_PANEL_ROWS - 1) / ABFT_PANEL_ROWS;
   const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
   const uint64_t nseg = ngroups * npanels;
   if (nseg == 0 || nseg > ((uint64_t)1 << 27)) return false;
-  for (int i = 1; i < nnz; i++)
-    if (rows[i] == rows[i - 1] && columns[i] < columns[i - 1]) return false;  // would reorder a row's additions
+  {
+    std::vector<uint32_t> last((size_t)n_out, 0);
+    for (int i = 0; i < nnz; i++) {
+      if (in_idx[i] < last[out_idx[i]]) return false;  // would reorder an output's additions
+      last[out_idx[i]] = in_idx[i];
+    }
+  }
+  auto segment = [&](int i) {
+    return (uint64_t)(out_idx[i] / ABFT_PANEL_ROWS) * npanels + std::min<uint64_t>(in_idx[i] / width, npanels - 1);
+  };
   pb.ngroups = (uint32_t)ngroups; pb.npanels = (uint32_t)npanels; pb.width = width;
   pb.seg_base.assign(nseg + 1, 0);
-  for (int i = 0; i < nnz; i++) {
-    const uint64_t seg = (uint64_t)(rows[i] / ABFT_PANEL_ROWS) * npanels + std::min<uint64_t>(columns[i] / width, npanels - 1);
-    pb.seg_base[seg + 1]++;
-  }
+  for (int i = 0; i < nnz; i++) pb.seg_base[segment(i) + 1]++;
   uint64_t nonempty = 0;
   for (uint64_t sgm = 0; sgm < nseg; sgm++) {
-    if (pb.seg_base[sgm + 1] > 65535u) return false;  // 16-bit row offsets
+    if (pb.seg_base[sgm + 1] > 65535u) return false;  // 16-bit offsets inside a segment
     nonempty += pb.seg_base[sgm + 1] != 0;
   }
-  if (!force && nonempty < 3 * ngroups) return false;  // a row group stays within a panel or two: banded
+  if (!force && nonempty < 3 * ngroups) return false;  // an output group stays within a panel or two: banded
   for (uint64_t sgm = 0; sgm < nseg; sgm++) pb.seg_base[sgm + 1] += pb.seg_base[sgm];
-  pb.pos.resize((size_t)nnz);
-  pb.orig.resize((size_t)nnz);
+  // per segment: offsets of each of its ABFT_PANEL_ROWS outputs (elements of one output contiguous)
   pb.seg_ptr.assign(nseg * (ABFT_PANEL_ROWS + 1), 0);
-  std::vector<uint32_t> fill(pb.seg_base.begin(), pb.seg_base.end() - 1);
-  for (int i = 0; i < nnz; i++) {
-    const uint64_t seg = (uint64_t)(rows[i] / ABFT_PANEL_ROWS) * npanels + std::min<uint64_t>(columns[i] / width, npanels - 1);
-    const uint32_t p = fill[seg]++;
-    pb.pos[i] = p;
-    pb.orig[p] = (uint32_t)i;
-    pb.seg_ptr[seg * (ABFT_PANEL_ROWS + 1) + rows[i] % ABFT_PANEL_ROWS + 1]++;
-  }
+  for (int i = 0; i < nnz; i++) pb.seg_ptr[segment(i) * (ABFT_PANEL_ROWS + 1) + out_idx[i] % ABFT_PANEL_ROWS + 1]++;
   for (uint64_t sgm = 0; sgm < nseg; sgm++) {
     uint16_t *p = pb.seg_ptr.data() + sgm * (ABFT_PANEL_ROWS + 1);
     for (int r = 0; r < ABFT_PANEL_ROWS; r++) p[r + 1] = (uint16_t)(p[r + 1] + p[r]);
+  }
+  // place: segment base + output's offset + arrival order within (segment, output)
+  pb.pos.resize((size_t)nnz);
+  pb.orig.resize((size_t)nnz);
+  std::vector<uint16_t> cursor(nseg * ABFT_PANEL_ROWS, 0);
+  for (int i = 0; i < nnz; i++) {
+    const uint64_t sgm = segment(i);
+    const uint32_t lo = out_idx[i] % ABFT_PANEL_ROWS;
+    const uint32_t p = pb.seg_base[sgm] + pb.seg_ptr[sgm * (ABFT_PANEL_ROWS + 1) + lo] + cursor[sgm * ABFT_PANEL_ROWS + lo]++;
+    pb.pos[i] = p;
+    pb.orig[p] = (uint32_t)i;
   }
   return true;
 }
@@ -363,7 +374,7 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
 
   // ---- layout: streaming row blocks (default) or column panels (scattered x) ----
   PanelBuild pb;
-  const bool panels = plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);
+  const bool panels = plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);  // gather index = column, output = row
   if (panels) {
     std::vector<uint32_t> pcols((size_t)nnz);
     std::vector<double> pvals((size_t)nnz);
@@ -434,8 +445,12 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   std::vector<uint32_t> orig((size_t)std::max(nnz, 1)), pos((size_t)std::max(nnz, 1));
   struct El { uint32_t col, row; double value; };
   std::vector<El> elems((size_t)std::max(nnz, 1));
+  // layout: grouped by output (default), or (output group, row panel) segments when
+  // the gathered vector is far larger than L2 and the row indices are scattered
+  PanelBuild pb;
+  const bool panels = plan_panels(mode, rows, columns, n_out, n_in, nnz, pb);  // gather index = row, output = column
   for (int i = 0; i < nnz; i++) {
-    const uint32_t p = fill[columns[i]]++;
+    const uint32_t p = panels ? pb.pos[i] : fill[columns[i]]++;
     elems[p] = El{columns[i], rows[i], values[i]};
     orig[p] = (uint32_t)i;
     pos[i] = p;
@@ -458,6 +473,20 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     return rc;
   }
   A.elems = d_el; A.grp_ptr = d_grp; A.blk = d_blk; A.orig_index = d_orig; A.pos_of_orig = d_pos;
+  if (panels) {
+    uint32_t *d_segbase = nullptr;
+    uint16_t *d_segptr = nullptr;
+    if ((rc = dev_upload(m, &d_segbase, pb.seg_base.data(), pb.seg_base.size(), pb.seg_base.size())) ||
+        (rc = dev_upload(m, &d_segptr, pb.seg_ptr.data(), pb.seg_ptr.size(), pb.seg_ptr.size()))) {
+      matrix_free(m);
+      return rc;
+    }
+    m->use_panels = true;
+    m->panels.seg_base = d_segbase;
+    m->panels.seg_ptr = d_segptr;
+    m->panels.ngroups = pb.ngroups;
+    m->panels.npanels = pb.npanels;
+  }
   hipError_t e = launch_encode_coo(mode, A.elems, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) {
@@ -485,8 +514,11 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
   abft_hip_matrix *m = *out;
   const uint32_t nblk = format == ABFT_FMT_CSR ? m->csr.nblk : m->coo.nblk;
   if (m->use_panels) {
-    const int per_cu = spmv_csr_panels_blocks_per_cu(mode, true);
+    const int per_cu = format == ABFT_FMT_CSR ? spmv_csr_panels_blocks_per_cu(mode, true) : 8;
     m->panel_grid = std::min<uint32_t>(m->panels.ngroups, (uint32_t)(per_cu * ctx->num_cus));
+    m->panel_chunk = 2;  // panels per launch: the kernel boundary keeps the chip in one 4 MB window of x
+    if (const char *e = getenv("ABFT_HIP_PANEL_CHUNK")) m->panel_chunk = (uint32_t)std::max(0L, atol(e));
+    if (m->panel_chunk) m->panel_grid = m->panels.ngroups;  // one row group per workgroup between boundaries
   }
   if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
     if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(nblk, 4096) * sizeof(double)) != hipSuccess) {
@@ -833,7 +865,11 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
     if (mat->fmt == ABFT_FMT_CSR && mat->use_panels) {
       nparts = mat->panel_grid;
       HIPCHK(launch_spmv_csr_panels(mat->mode, mat->csr, mat->panels, vec->d, result->d, ctx->ring,
-                                    do_fuse ? &fuse : nullptr, mat->panel_grid, ctx->stream));
+                                    do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
+    } else if (mat->fmt == ABFT_FMT_COO && mat->use_panels) {
+      nparts = mat->panel_grid;
+      HIPCHK(launch_spmv_coo_panels(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
+                                    do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
     } else if (mat->fmt == ABFT_FMT_CSR)
       HIPCHK(launch_spmv_csr(mat->mode, mat->csr, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
     else

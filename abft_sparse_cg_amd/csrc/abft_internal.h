@@ -133,8 +133,12 @@ struct FuseOut {
 
 // panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
 hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,
-                                  EventRing ev, const FuseOut *fuse, uint32_t grid, hipStream_t s);
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
+                                  hipStream_t s);
 int spmv_csr_panels_blocks_per_cu(int mode, bool fuse);
+hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y,
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
+                                  hipStream_t s);
 // fuse == nullptr: plain SpMV; otherwise follow with launch_fuse_finalize
 hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s);
 hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,

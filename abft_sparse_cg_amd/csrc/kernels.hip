@@ -467,7 +467,9 @@ template <int MODE, int EPT, bool FUSE>
 __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, CsrPanels P,
                                                                      const double *__restrict__ x,
                                                                      double *__restrict__ y, EventRing ev,
-                                                                     FuseOut fuse) {
+                                                                     FuseOut fuse, uint32_t c0, uint32_t c1) {
+  // panels [c0, c1) in this launch; a launch that does not start at panel 0
+  // resumes from the row sums the previous launch left in y (exact: fp64 stores)
   constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
@@ -477,8 +479,11 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
     const uint32_t row0 = g * ABFT_PANEL_ROWS;
     double acc[RPT];
 #pragma unroll
-    for (int j = 0; j < RPT; j++) acc[j] = 0.0;
-    for (uint32_t c = 0; c < P.npanels; c++) {
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t row = row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      acc[j] = (c0 > 0 && row < A.n_out) ? y[row] : 0.0;
+    }
+    for (uint32_t c = c0; c < c1; c++) {
       const uint32_t seg = g * P.npanels + c;
       const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
       if (e0 == e1) continue;  // uniform
@@ -522,27 +527,40 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
 
 template <int MODE>
 static hipError_t launch_panels_mode(const CsrDev &A, const CsrPanels &P, const double *x, double *y,
-                                     EventRing ev, const FuseOut *fuse, uint32_t grid, hipStream_t s) {
+                                     EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1,
+                                     hipStream_t s) {
   if (fuse)
     hipLaunchKernelGGL((spmv_csr_panels_kernel<MODE, ABFT_CFG_PANEL_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0,
-                       s, A, P, x, y, ev, *fuse);
+                       s, A, P, x, y, ev, *fuse, c0, c1);
   else
     hipLaunchKernelGGL((spmv_csr_panels_kernel<MODE, ABFT_CFG_PANEL_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0,
-                       s, A, P, x, y, ev, FuseOut{});
+                       s, A, P, x, y, ev, FuseOut{}, c0, c1);
   return hipGetLastError();
 }
 
+// `chunk` panels per launch (0: all in one launch).  The kernel boundary between
+// chunks is what keeps every workgroup of the chip in the same window of x; the
+// fused dot rides on the last chunk only.
 hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,
-                                  EventRing ev, const FuseOut *fuse, uint32_t grid, hipStream_t s) {
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
+                                  hipStream_t s) {
   if (P.ngroups == 0) return hipSuccess;
-  switch (mode) {
-    case MODE_NONE: return launch_panels_mode<MODE_NONE>(A, P, x, y, ev, fuse, grid, s);
-    case MODE_SED: return launch_panels_mode<MODE_SED>(A, P, x, y, ev, fuse, grid, s);
-    case MODE_SEC7: return launch_panels_mode<MODE_SEC7>(A, P, x, y, ev, fuse, grid, s);
-    case MODE_SEC8: return launch_panels_mode<MODE_SEC8>(A, P, x, y, ev, fuse, grid, s);
-    case MODE_SECDED: return launch_panels_mode<MODE_SECDED>(A, P, x, y, ev, fuse, grid, s);
-    default: return hipErrorInvalidValue;
+  if (chunk == 0 || chunk > P.npanels) chunk = P.npanels;
+  for (uint32_t c0 = 0; c0 < P.npanels; c0 += chunk) {
+    const uint32_t c1 = c0 + chunk < P.npanels ? c0 + chunk : P.npanels;
+    const FuseOut *f = c1 == P.npanels ? fuse : nullptr;
+    hipError_t e;
+    switch (mode) {
+      case MODE_NONE: e = launch_panels_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SED: e = launch_panels_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC7: e = launch_panels_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC8: e = launch_panels_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SECDED: e = launch_panels_mode<MODE_SECDED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
   }
+  return hipSuccess;
 }
 
 template <int MODE, bool FUSE> static int panels_occupancy() {
@@ -724,6 +742,115 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
     }
   }
   if (FUSE) fused_dot_finish(dsum, fuse);
+}
+
+// continue an ordered sum over LDS slots [a, b) from `acc` (see lds_ordered_sum)
+__device__ __forceinline__ void lds_ordered_add(const double *s_prod, uint32_t a, uint32_t b, double &acc) {
+  for (uint32_t k = a; k < b; k += 4u) {
+    const uint32_t last = b - 1u;
+    const double a0 = s_prod[k], a1 = s_prod[min(k + 1u, last)], a2 = s_prod[min(k + 2u, last)],
+                 a3 = s_prod[min(k + 3u, last)];
+    acc += a0;
+    if (k + 1u < b) acc += a1;
+    if (k + 2u < b) acc += a2;
+    if (k + 3u < b) acc += a3;
+  }
+}
+
+// Panel-layout COO SpMV: the CSR panel kernel with (output group, row panel)
+// segments of 16-byte elements; outputs are the reference's result[col], the
+// gather index is the element's row (COO/CPUContext.cpp:111-120).
+template <int MODE, int EPT, bool FUSE>
+__global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, CsrPanels P,
+                                                                     const double *__restrict__ x,
+                                                                     double *__restrict__ y, EventRing ev,
+                                                                     FuseOut fuse, uint32_t c0, uint32_t c1) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  double dsum = 0.0;
+  for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x) {
+    const uint32_t out0 = g * ABFT_PANEL_ROWS;
+    double acc[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
+    }
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t seg = g * P.npanels + c;
+      const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+      if (e0 == e1) continue;  // uniform
+      const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+      uint32_t gs[RPT], ge[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        const uint32_t r = (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+        gs[j] = e0 + ptr[r];
+        ge[j] = e0 + ptr[r + 1];
+      }
+      for (uint32_t lo = e0; lo < e1;) {
+        const uint32_t hi = min(e1, lo + TILE);
+        __syncthreads();
+        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+          const uint32_t a0 = max(gs[j], lo), a1 = min(ge[j], hi);
+          if (a0 < a1) {
+            double t = acc[j];
+            lds_ordered_add(s_prod, a0 - lo, a1 - lo, t);
+            acc[j] = t;
+          }
+        }
+        lo = hi;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      if (o < A.n_out) {
+        y[o] = acc[j];
+        if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
+      }
+    }
+  }
+  if (FUSE) fused_dot_finish(dsum, fuse);
+}
+
+template <int MODE>
+static hipError_t launch_coo_panels_mode(const CooDev &A, const CsrPanels &P, const double *x, double *y,
+                                         EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0,
+                                         uint32_t c1, hipStream_t s) {
+  if (fuse)
+    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_COO_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
+                       P, x, y, ev, *fuse, c0, c1);
+  else
+    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_COO_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
+                       P, x, y, ev, FuseOut{}, c0, c1);
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y,
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
+                                  hipStream_t s) {
+  if (P.ngroups == 0) return hipSuccess;
+  if (chunk == 0 || chunk > P.npanels) chunk = P.npanels;
+  for (uint32_t c0 = 0; c0 < P.npanels; c0 += chunk) {
+    const uint32_t c1 = c0 + chunk < P.npanels ? c0 + chunk : P.npanels;
+    const FuseOut *f = c1 == P.npanels ? fuse : nullptr;
+    hipError_t e;
+    switch (mode) {
+      case MODE_NONE: e = launch_coo_panels_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SED: e = launch_coo_panels_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC7: e = launch_coo_panels_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC8: e = launch_coo_panels_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SECDED: e = launch_coo_panels_mode<MODE_SECDED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 template <int MODE>
