@@ -21,6 +21,11 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   rocprofv3 --pmc $c -f csv -d $O/pmcr_$n -- $B --steps 5 --warmup 1 --no-profile --mode secded --spec random:4194304,24,1 > /dev/null 2> $O/pmcr_$n.err
   python3 profiles/summarize.py pmc $O/pmcr_$n $O/pmc_${n}_random_secded.json > /dev/null
 done
+rocprofv3 --kernel-trace --stats -f csv -d $O/trace_rand -- $B --steps 30 --mode secded --spec random:4194304,24,1 > $O/bench_under_trace_random_secded.json 2> $O/trace3.err
+python3 profiles/summarize.py trace $O/trace_rand $O/kernel_trace_random_secded.md
+rocprofv3 --kernel-trace --stats -f csv -d $O/trace_coo -- $B --steps 50 --fmt coo --mode sec7 --spec powerlaw:2097152,2 > $O/bench_under_trace_coo_sec7.json 2> $O/trace4.err
+python3 profiles/summarize.py trace $O/trace_coo $O/kernel_trace_powerlaw_coo_sec7.md
+rm -rf $O/trace_rand $O/trace_coo
 rm -rf $O/trace $O/trace_secded $O/pmc_fetch_size $O/pmc_write_size $O/pmc_tcc_hit_sum $O/pmcr_fetch_size $O/pmcr_write_size $O/pmcr_tcc_hit_sum
 cat $O/kernel_trace_laplace_none.md
 ls $O
