@@ -449,3 +449,41 @@ def test_fused_dot_is_transparent(amd, fmt):
         assert seen == [(2, 3, 5)]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("width,chunk", [(16, 0), (16, 3), (257, 1), (100000, 2)])
+def test_panel_layout_forced_on_small_matrices(amd, fmt, width, chunk, monkeypatch):
+    """The panel (column-blocked) layout is normally chosen only for large
+    scattered matrices (exercised at full size in test_gpu_fullsize); force it
+    here, with tiny panels and several launch chunkings, through the same checks:
+    stored elements come back in the caller's order, SpMV is bit-identical, every
+    single-bit flip is reported with the caller's element index and repaired."""
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "panels")
+    monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", str(width))
+    monkeypatch.setenv("ABFT_HIP_PANEL_CHUNK", str(chunk))
+    for mat in ("ragged", "rnd300", "lap40"):
+        cols, rows, vals, n = MATS[mat]()
+        x = rhs(n, 11) - 0.5
+        for mode in ("none", "secded"):
+            o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+            h = Hip(amd, fmt, mode, cols, rows, vals, n)
+            try:
+                assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+                assert bits_equal(h.spmv(x), o.spmv(x))
+                assert h.take_events() == ([], False)
+                if mode == "secded":
+                    idx = [0, len(vals) // 2, len(vals) - 1]
+                    for k, i in enumerate(idx):
+                        o.inject(i, [7 + 30 * k])
+                        h.ctx.inject_at(h.A, i, [7 + 30 * k])
+                    assert bits_equal(h.spmv(x), o.spmv(x))
+                    assert h.take_events() == o.events()
+                    assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+                    # fused dot through the panel kernel
+                    h.ctx.spmv(h.A, h.vx, h.vy)
+                    d = h.ctx.dot(h.vx, h.vy)
+                    y = h.ctx.download(h.vy)
+                    assert abs(d - ora_dot(x, y)) <= 1e-13 * float(np.abs(x * y).sum())
+            finally:
+                h.close()
