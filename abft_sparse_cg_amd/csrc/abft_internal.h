@@ -42,7 +42,10 @@ struct CsrPanels {
   const uint16_t *seg_ptr;   // per segment ABFT_PANEL_ROWS + 1 row offsets relative to seg_base
   uint32_t ngroups, npanels;
 };
-constexpr int ABFT_PANEL_ROWS_PER_THREAD = 4;
+#ifndef ABFT_CFG_PANEL_RPT
+#define ABFT_CFG_PANEL_RPT 8  // outputs per thread of the panel kernels (4: equal on config 4, -14% on config 5)
+#endif
+constexpr int ABFT_PANEL_ROWS_PER_THREAD = ABFT_CFG_PANEL_RPT;
 constexpr int ABFT_PANEL_ROWS = 256 * ABFT_PANEL_ROWS_PER_THREAD;
 
 // COO matrix: 16-byte elements {col,row,value} (COO/ecc.h:11-16) stored grouped
