@@ -1,0 +1,101 @@
+"""Host-side logic that needs no GPU: the Matrix-Market loader dialect
+(cg.cpp:342-418), the glibc-rand right-hand side, the Python CLI's argument
+handling (cg.cpp:180-309), and the panel/partition helpers."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MTX = os.path.join(ROOT, "tests", "golden", "lap64.mtx")
+
+
+@pytest.fixture(scope="module")
+def gen():
+    sys.path.insert(0, ROOT)
+    from abft_sparse_cg_amd import generators  # plain C++ library: no HIP involved
+    return generators
+
+
+def test_loader_mirrors_sorts_and_tiles(gen, tmp_path):
+    p = tmp_path / "t.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real symmetric\n% comment\n%another\n"
+                 "3 3 4\n1 1 2.5\n2 1 -1\n3 3 7\n3 2 0.5\n")
+    cols, rows, vals, n, block = gen.load_mtx(str(p), 1)
+    assert (n, block) == (3, 3)
+    # off-diagonals mirrored, sorted by (row, col); first integer of a line is the COLUMN (cg.cpp:371-381)
+    assert list(zip(rows, cols, vals)) == [(0, 0, 2.5), (0, 1, -1.0), (1, 0, -1.0), (1, 2, 0.5), (2, 1, 0.5), (2, 2, 7.0)]
+    cols2, rows2, vals2, n2, block2 = gen.load_mtx(str(p), 3)  # -b 3: the block down the diagonal
+    assert (n2, block2, len(vals2)) == (9, 3, 18)
+    for j in range(3):
+        s = slice(6 * j, 6 * j + 6)
+        assert np.array_equal(cols2[s], cols + 3 * j) and np.array_equal(rows2[s], rows + 3 * j)
+        assert np.array_equal(vals2[s], vals)
+
+
+def test_loader_errors(gen, tmp_path):
+    with pytest.raises(FileNotFoundError):
+        gen.load_mtx(str(tmp_path / "missing.mtx"), 1)
+    p = tmp_path / "rect.mtx"
+    p.write_text("%%MatrixMarket\n3 4 1\n1 1 1\n")
+    with pytest.raises(ValueError, match="not square"):
+        gen.load_mtx(str(p), 1)
+    p = tmp_path / "short.mtx"
+    p.write_text("%%MatrixMarket\n3 3 2\n1 1 1\n")
+    with pytest.raises(ValueError, match="Failed to read"):
+        gen.load_mtx(str(p), 1)
+
+
+def test_committed_laplacian_file_is_what_the_generator_makes(gen):
+    cols, rows, vals, n, block = gen.load_mtx(MTX, 1)
+    c2, r2, v2, n2 = gen.generate("laplace5:64,64")
+    assert n == n2 == 4096 and np.array_equal(cols, c2) and np.array_equal(rows, r2) and np.array_equal(vals, v2)
+
+
+def test_reference_rhs_is_glibc_rand(gen):
+    libc = ctypes.CDLL(None)
+    for seed in (1, 77):
+        libc.srand(seed)
+        want = np.array([libc.rand() for _ in range(3000)]) / 2147483647.0
+        assert np.array_equal(gen.reference_rhs(3000, seed), want)
+
+
+def run_cli(args):
+    return subprocess.run([sys.executable, "-m", "abft_sparse_cg_amd.cg"] + args, capture_output=True, text=True,
+                          cwd=ROOT, timeout=300)
+
+
+def test_python_cli_argument_handling_without_a_gpu():
+    out = run_cli(["--list"])
+    assert out.returncode == 0
+    assert out.stdout == "\nRegistered contexts:\n" + "".join(
+        "\thip-%s\n" % m for m in ("none", "constraints", "sed", "sec7", "sec8", "secded", "sec")) + "\n"
+    out = run_cli(["--bogus"])
+    assert out.returncode == 1 and out.stdout == "Unrecognized argument '--bogus' (try '--help')\n"
+    out = run_cli(["-i", "x"])
+    assert out.returncode == 1 and out.stdout == "Invalid number of iterations\n"
+    out = run_cli(["-b", "0"])
+    assert out.returncode == 1 and out.stdout == "Invalid number of blocks\n"
+    out = run_cli(["-c"])
+    assert out.returncode == 1 and out.stdout == "Invalid convergence threshold\n"
+    out = run_cli(["-t", "cpu"])
+    assert out.returncode == 1 and "No implementation found for cpu-none" in out.stderr
+    out = run_cli(["-m", "nonsense"])
+    assert out.returncode == 1 and "No implementation found for hip-nonsense" in out.stderr
+    out = run_cli(["-f", "/nonexistent.mtx"])
+    assert out.returncode == 1 and out.stdout == "Failed to open '/nonexistent.mtx'\n"
+    out = run_cli(["--help"])
+    assert out.returncode == 0 and "--inject-bitflip" in out.stdout and "--synthetic" in out.stdout
+
+
+def test_flip_draw_ranges_follow_the_reference():
+    sys.path.insert(0, ROOT)
+    from abft_sparse_cg_amd.cg import bit_range
+    # CSR: [0,64) value, [64,96) column (CSR/CPUContext.cpp:139-144); COO: [0,64) indices, [64,128) value
+    assert bit_range("csr", "ANY") == (0, 96) and bit_range("csr", "VALUE") == (0, 64)
+    assert bit_range("csr", "INDEX") == (64, 96)
+    assert bit_range("coo", "ANY") == (0, 128) and bit_range("coo", "VALUE") == (64, 128)
+    assert bit_range("coo", "INDEX") == (0, 64)
