@@ -1,8 +1,11 @@
 // kernels.hip -- hand-written CDNA4 (gfx950) kernels of the ABFT sparse-CG hot
 // path.  Everything here is HBM-bound integer/fp64 work: no MFMA; the levers
 // are coalesced streaming of cols/vals, LDS-staged per-row partial products,
-// XCD-aware tile order so each XCD's L2 keeps its own window of x, 64-lane
-// wave reductions, and the ECC check folded into the load path.
+// XCD-aware tile order so each XCD's L2 keeps its own window of x, column
+// panels for matrices whose gathers would otherwise miss L2, 64-lane wave
+// reductions with a deterministic last-block fold, and the ECC check folded
+// into the load path.  Design notes and the measurements behind each choice:
+// DESIGN.md section 4.
 //
 // Numerics: compiled with -ffp-contract=off.  SpMV sums every row in ascending
 // element order with separate multiply and add, so y is bit-identical to the

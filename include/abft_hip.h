@@ -160,7 +160,13 @@ int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
 int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r,
                     double beta);
 /* reference CSR/CPUContext.cpp:115-133 and the five ABFT variants :162-411;
- * COO/CPUContext.cpp:104-121 and :142-379.  The mode is the matrix's. */
+ * COO/CPUContext.cpp:104-121 and :142-379.  The mode is the matrix's.
+ * On a square matrix the kernel also forms sum vec[row]*result[row]; an
+ * abft_hip_dot(vec, result) issued before either vector changes is answered
+ * from it (same API, one pass over the vectors less; ABFT_HIP_FUSE_DOT=0 turns
+ * it off).  Large matrices with scattered columns are stored in a column-panel
+ * layout chosen at create time (ABFT_HIP_LAYOUT=stream|panels|auto); element
+ * indices seen by the caller (events, inject, read-back) are unaffected. */
 int abft_hip_spmv(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                   abft_hip_vector *result);
 
