@@ -521,7 +521,9 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
     if (m->panel_chunk) m->panel_grid = m->panels.ngroups;  // one row group per workgroup between boundaries
   }
   if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
-    if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(nblk, 4096) * sizeof(double)) != hipSuccess) {
+    // one partial per SpMV workgroup: row blocks (streaming) or output groups (panels)
+    const uint32_t max_parts = std::max(nblk, m->use_panels ? std::max(m->panel_grid, m->panels.ngroups) : 0u);
+    if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(max_parts, 1) * sizeof(double)) != hipSuccess) {
       matrix_free(m);
       *out = nullptr;
       return set_err(ABFT_ERR_NOMEM, "fusion buffer for %u blocks does not fit", nblk);
