@@ -204,3 +204,29 @@ def test_config5_powerlaw_coo_sec7_full_size(amd, gen):
     finally:
         c.close()
         k.close()
+
+
+def test_panel_layout_on_config2_matches_streaming_layout(amd, gen, monkeypatch):
+    """10 M rows = 4 883 output groups of the panel kernels (more workgroups than
+    the fused-dot fold's first block): y and the fused p.w must equal the streaming
+    layout's, bit for bit / to reduction tolerance."""
+    mat = gen.generate(LAP)
+    cols, rows, vals, n = mat
+    x = np.random.default_rng(8).standard_normal(n)
+    ref = Run(amd, "csr", "sec8", mat)
+    try:
+        y0 = ref.spmv(x)
+        d0 = ref.ctx.dot(ref.vx, ref.vy)
+    finally:
+        ref.close()
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "panels")
+    pan = Run(amd, "csr", "sec8", mat)
+    try:
+        y1 = pan.spmv(x)
+        d1 = pan.ctx.dot(pan.vx, pan.vy)  # served by the panel kernel's fused epilogue
+        assert bits_equal(y1, y0)
+        assert abs(d1 - d0) <= 1e-12 * float(np.abs(x * y0).sum())
+        pan.ctx.inject_at(pan.A, 31415926, [9])
+        assert bits_equal(pan.spmv(x), y0) and pan.events == [(2, 31415926, 9)]
+    finally:
+        pan.close()
