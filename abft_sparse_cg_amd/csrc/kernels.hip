@@ -253,12 +253,12 @@ template <int EPT> struct CsrTileRegs {
 };
 
 // the streaming loads of one tile: no branches, out-of-tile lanes re-read the first pair
-template <int EPT, int BLOCK = ABFT_BLOCK>
+template <int EPT>
 __device__ __forceinline__ void csr_issue_loads(const CsrDev &A, uint32_t base, uint32_t hi,
-                                                CsrTileRegs<EPT> &t, uint32_t tid) {
+                                                CsrTileRegs<EPT> &t) {
 #pragma unroll
   for (int s = 0; s < EPT / 2; s++) {
-    const uint32_t i = base + 2u * tid + (uint32_t)s * (2u * BLOCK);
+    const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
     const uint32_t ii = i < hi ? i : base;  // always a valid, even element index
     t.v[s] = STREAM_LOAD(reinterpret_cast<const f64x2 *>(A.vals + ii));
     t.c[s] = STREAM_LOAD(reinterpret_cast<const u32x2 *>(A.cols + ii));
@@ -272,12 +272,12 @@ __device__ __forceinline__ void csr_issue_loads(const CsrDev &A, uint32_t base, 
 // kernel built on this was measured and dropped: 180 us vs 151 us for one tile
 // per workgroup (config 2) -- 8 resident workgroups per CU already overlap each
 // other's phases, and the extra registers cost occupancy.
-template <int MODE, int EPT, int BLOCK = ABFT_BLOCK>
+template <int MODE, int EPT>
 __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__restrict__ x,
                                             const EventRing &ev, uint32_t base, uint32_t lo,
                                             uint32_t hi, const CsrTileRegs<EPT> &t, double *s_prod,
                                             uint32_t *s_col, bool prefetch, uint32_t nbase, uint32_t nhi,
-                                            CsrTileRegs<EPT> &nxt, uint32_t tid) {
+                                            CsrTileRegs<EPT> &nxt) {
   constexpr int STEPS = EPT / 2;
   uint32_t col[EPT];
   double val[EPT];
@@ -285,7 +285,7 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
 #pragma unroll
   for (int j = 0; j < EPT; j++) {
     const int s = j >> 1;
-    const uint32_t i = base + 2u * tid + (uint32_t)s * (2u * BLOCK) + (uint32_t)(j & 1);
+    const uint32_t i = base + 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK) + (uint32_t)(j & 1);
     const double d = (j & 1) ? t.v[s].y : t.v[s].x;
     uint32_t w[3] = {(uint32_t)__double2loint(d), (uint32_t)__double2hiint(d), (j & 1) ? t.c[s].y : t.c[s].x};
     bool valid = i >= lo && i < hi;
@@ -319,10 +319,10 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
   // no branch around the prefetch: with one, hipcc drains the whole memory queue
   // (vmcnt(0)) at the join and the overlap is gone; a caller with nothing to
   // prefetch passes nhi == nbase, which makes every lane re-read one resident pair
-  if (prefetch) csr_issue_loads<EPT, BLOCK>(A, nbase, nhi, nxt, tid);
+  if (prefetch) csr_issue_loads<EPT>(A, nbase, nhi, nxt);
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
-    const uint32_t k = 2u * tid + (uint32_t)s * (2u * BLOCK);
+    const uint32_t k = 2u * threadIdx.x + (uint32_t)s * (2u * ABFT_BLOCK);
     const double p0 = val[2 * s] * xv[2 * s], p1 = val[2 * s + 1] * xv[2 * s + 1];
     *reinterpret_cast<double2 *>(s_prod + k) = make_double2(ok[2 * s] ? p0 : 0.0, ok[2 * s + 1] ? p1 : 0.0);
     if (MODE == MODE_CONSTRAINTS)
@@ -331,14 +331,13 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
 }
 
 // load + consume of one tile (the non-pipelined form)
-template <int MODE, int EPT, int BLOCK = ABFT_BLOCK>
+template <int MODE, int EPT>
 __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restrict__ x,
                                           const EventRing &ev, uint32_t base, uint32_t lo,
-                                          uint32_t hi, double *s_prod, uint32_t *s_col,
-                                          uint32_t tid = threadIdx.x) {
+                                          uint32_t hi, double *s_prod, uint32_t *s_col) {
   CsrTileRegs<EPT> t, unused;
-  csr_issue_loads<EPT, BLOCK>(A, base, hi, t, tid);
-  csr_consume<MODE, EPT, BLOCK>(A, x, ev, base, lo, hi, t, s_prod, s_col, false, 0u, 0u, unused, tid);
+  csr_issue_loads<EPT>(A, base, hi, t);
+  csr_consume<MODE, EPT>(A, x, ev, base, lo, hi, t, s_prod, s_col, false, 0u, 0u, unused);
 }
 
 // Sum one row from the staged products, in ascending element order.  In
@@ -461,15 +460,12 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
   if (FUSE) fused_dot_finish(dsum, fuse);
 }
 
-// Panel-layout CSR SpMV (see CsrPanels).  A workgroup takes output groups g,
-// g + gridDim.x, ... and, per group, walks the panels [c0, c1) in ascending
-// order with the row sums of every thread held in registers.  The four waves of
-// a workgroup work independently: wave w owns rows [w*R/4, (w+1)*R/4) of the
-// group -- whose elements are one contiguous range of the segment, read off the
-// 16-bit row offsets -- stages them through its own LDS slice with the same
-// branch-free load phase as the streaming kernel (64-lane form) and adds the
-// staged products of its lanes' rows in element order.  No workgroup barrier:
-// LDS traffic of one wave is ordered by the wave itself.
+// Panel-layout CSR SpMV (see CsrPanels).  Persistent workgroups: each takes row
+// groups g, g + gridDim.x, ... and, per group, sweeps the column panels in
+// ascending order with the 4 row sums of every thread held in registers.  A
+// segment is staged through LDS by the same branch-free load phase as the
+// streaming kernel (fully coalesced, ECC in registers); each thread then adds
+// the staged products of its rows, in element order, onto its running sums.
 template <int MODE, int EPT, bool FUSE>
 __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, CsrPanels P,
                                                                      const double *__restrict__ x,
@@ -477,45 +473,37 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
                                                                      FuseOut fuse, uint32_t c0, uint32_t c1) {
   // panels [c0, c1) in this launch; a launch that does not start at panel 0
   // resumes from the row sums the previous launch left in y (exact: fp64 stores)
-  constexpr uint32_t WTILE = 64 * EPT;  // elements staged per wave
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
-  constexpr uint32_t WROWS = 64 * RPT;  // rows per wave
-  __shared__ __attribute__((aligned(16))) double s_prod_all[4][WTILE];
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  double *s_prod = s_prod_all[wave];
   double dsum = 0.0;
   for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x) {
-    const uint32_t row0 = g * ABFT_PANEL_ROWS + wave * WROWS;
+    const uint32_t row0 = g * ABFT_PANEL_ROWS;
     double acc[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
-      const uint32_t row = row0 + (uint32_t)j * 64u + lane;
+      const uint32_t row = row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
       acc[j] = (c0 > 0 && row < A.n_out) ? y[row] : 0.0;
     }
     for (uint32_t c = c0; c < c1; c++) {
       const uint32_t seg = g * P.npanels + c;
-      const uint32_t e0 = P.seg_base[seg];
-      const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1) + wave * WROWS;
-      const uint32_t ws = e0 + ptr[0], we = e0 + ptr[WROWS];  // this wave's elements (wave-uniform)
-      if (ws == we) continue;
+      const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+      if (e0 == e1) continue;  // uniform
+      const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
       uint32_t rs[RPT], re[RPT];
 #pragma unroll
-      for (int j = 0; j < RPT; j++) {  // this lane's rows: row0 + j*64 + lane
-        const uint32_t r = (uint32_t)j * 64u + lane;
+      for (int j = 0; j < RPT; j++) {  // this thread's rows: row0 + j*256 + tid
+        const uint32_t r = (uint32_t)j * ABFT_BLOCK + threadIdx.x;
         rs[j] = e0 + ptr[r];
         re[j] = e0 + ptr[r + 1];
       }
-      for (uint32_t lo = ws; lo < we;) {
+      for (uint32_t lo = e0; lo < e1;) {
         const uint32_t b = lo & ~1u;
-        const uint32_t hi = min(we, b + WTILE);
-        // one wave's LDS operations execute in program order; the fences only stop
-        // the compiler from moving the tile's reads and writes across each other
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        csr_stage<MODE, EPT, 64>(A, x, ev, b, lo, hi, s_prod, s_col, lane);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        const uint32_t hi = min(e1, b + TILE);
+        __syncthreads();
+        csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
           const uint32_t a0 = max(rs[j], lo), a1 = min(re[j], hi);
@@ -530,7 +518,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
     }
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
-      const uint32_t row = row0 + (uint32_t)j * 64u + lane;
+      const uint32_t row = row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
       if (row < A.n_out) {
         y[row] = acc[j];
         if (FUSE) dsum += x[fuse.x_off + row] * acc[j];
