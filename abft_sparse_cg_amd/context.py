@@ -62,6 +62,7 @@ class HIPContext:
         check(self.L.abft_hip_init(device, C.byref(h)))
         self.h = h
         self.event_log = []
+        self.prof_mask = 0
 
     def close(self):
         if self.h:
@@ -226,7 +227,8 @@ class HIPContext:
     # ---- measurement ------------------------------------------------------
     def profile(self, mask=0xF):
         """bit k of mask brackets kernel k (capi.K_*) with HIP events; 0 = off"""
-        check(self.L.abft_hip_profile_enable(self.h, 0xF if mask is True else int(mask)))
+        self.prof_mask = 0xF if mask is True else int(mask)
+        check(self.L.abft_hip_profile_enable(self.h, self.prof_mask))
         check(self.L.abft_hip_profile_reset(self.h))
 
     def profile_read(self, kernel):

@@ -23,6 +23,7 @@ is the one the north star names:
 The compute engine is a parameter: the product passes HipEngine (the C ABI);
 tests pass a CPU stand-in to exercise the partition/collective logic under gloo.
 """
+import os
 import sys
 
 import numpy as np
@@ -141,6 +142,10 @@ class ShardedCG:
         move device memory (gloo), e.g. several ranks sharing one GPU in tests."""
         self.e, self.group, self.mode, self.fmt_id = engine, group, mode, fmt_id
         self.staged = staged
+        # measurement aid: issue the collectives even at world size 1 (their host-side cost is the same)
+        self.force_coll = os.environ.get("ABFT_FORCE_COLLECTIVES") == "1"
+        self._graph = None  # hipGraph of two iterations (run_fixed); False once capture has failed
+        self._warm = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         assert len(bounds) == self.G + 1
@@ -195,7 +200,7 @@ class ShardedCG:
     # ---- collectives -------------------------------------------------------
     def exchange(self, full_vec_tensor):
         """Fill the peers' slots of a gathered buffer whose own slot is current."""
-        if self.G == 1:
+        if self.G == 1 and not self.force_coll:
             return
         S, me = self.slot, self.rank
         if self.staged:
@@ -296,38 +301,90 @@ class ShardedCG:
         self.rr = rr_new
         return rr_new
 
-    def run_fixed(self, iters):
+    def run_fixed(self, iters, graph=None):
         """`iters` CG iterations with no convergence test (-c 0), alpha and beta
         resident on the device: each iteration enqueues exchange, spmv+dot,
         all-reduce, calc_xr, all-reduce, calc_p and reads nothing back, so the host
         never waits inside the loop (at 8 GPUs the local kernels take ~40 us and a
         host round trip per scalar would dominate).  Same kernels, same arithmetic
         (alpha = rr/pw and beta = rr_new/rr formed in fp64 on the device) as step().
+
+        graph (default: on, unless ABFT_CG_GRAPH=0 or the collectives are host-staged):
+        an iteration -- kernels, the two all-reduces and, in all-gather mode, the
+        exchange -- is captured once into a hipGraph on the shared stream (two graphs:
+        the rr / rr_new scalars swap roles every iteration) and replayed, so the host
+        issues one launch per iteration instead of ~8 calls.  Point-to-point window
+        copies stay outside the graph and are issued eagerly between replays.  The
+        first two iterations of the first call run eagerly (communicators and peer
+        connections are set up by their first use, which must not happen under
+        capture); if capture is refused the loop carries on eagerly.
+
         ECC events are collected once, at the end.  Returns the final rr."""
         if not hasattr(self, "_pipe"):
             vecs = [self.e.create_vector(2) for _ in range(3)]
             self._pipe = [(v, self.e.tensor(v)) for v in vecs]
-        (cur, t_cur), (nxt, t_nxt), (pw, t_pw) = self._pipe
+        if graph is None:
+            graph = os.environ.get("ABFT_CG_GRAPH", "1") != "0"
+        # (HIP-event brackets around kernels cannot be captured: profiling turns the graph off)
+        graph = graph and not self.staged and hasattr(self.e, "tstream") and not self.e.ctx.prof_mask
+        s0, s1, pw = self._pipe
         self.e.copy(self.r, self.b)
         self.e.copy(self.p, self.r)
-        self.e.dot_partial(self.r, self.r, cur)
-        self._allreduce_async(t_cur)
-        for _ in range(iters):
-            self.exchange(self.t_full)
-            self.e.spmv_dot(self.A, self.p_full, self.rank * self.slot, self.w, pw)
-            self._allreduce_async(t_pw)
-            self.e.calc_xr_ratio(self.x, self.r, self.p, self.w, cur, pw, nxt)
-            self._allreduce_async(t_nxt)
-            self.e.calc_p_ratio(self.p, self.r, nxt, cur)
-            (cur, t_cur), (nxt, t_nxt) = (nxt, t_nxt), (cur, t_cur)
-        v = (t_cur.cpu() if self.staged else t_cur).tolist()  # the only synchronisation
+        self.e.dot_partial(self.r, self.r, s0[0])
+        self._allreduce_async(s0[1])
+        left, k = iters, 0
+        if graph and not self._warm and left >= 2:
+            self._iteration(s0, s1, pw)
+            self._iteration(s1, s0, pw)
+            self._warm = True
+            left -= 2
+        if graph and self._warm and left and self._graph is None:
+            self._capture(s0, s1, pw)
+        if graph and self._graph:
+            while left:
+                if self.use_windows:
+                    self.exchange(self.t_full)
+                self._graph[k & 1].replay()
+                k += 1
+                left -= 1
+        pair = (s0, s1)
+        for _ in range(left):
+            self._iteration(pair[k & 1], pair[1 - (k & 1)], pw)
+            k += 1
+        self._warm = True
+        cur = pair[k & 1]
+        v = (cur[1].cpu() if self.staged else cur[1]).tolist()  # the only synchronisation
         self.rr = v[0]
         if int(v[1]) and self._collect_events():
             raise SystemExit(1)
         return self.rr
 
+    def _iteration(self, cur, nxt, pw, exchange=True):
+        """enqueue one iteration: rr in cur -> rr_new in nxt"""
+        if exchange:
+            self.exchange(self.t_full)
+        self.e.spmv_dot(self.A, self.p_full, self.rank * self.slot, self.w, pw[0])
+        self._allreduce_async(pw[1])
+        self.e.calc_xr_ratio(self.x, self.r, self.p, self.w, cur[0], pw[0], nxt[0])
+        self._allreduce_async(nxt[1])
+        self.e.calc_p_ratio(self.p, self.r, nxt[0], cur[0])
+
+    def _capture(self, s0, s1, pw):
+        graphs = []
+        try:
+            for cur, nxt in ((s0, s1), (s1, s0)):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=self.e.tstream, capture_error_mode="thread_local"):
+                    self._iteration(cur, nxt, pw, exchange=not self.use_windows)
+                graphs.append(g)
+            self._graph = graphs
+        except Exception as exc:  # capture refused: keep going without it
+            sys.stderr.write("abft: hipGraph capture of the CG iteration failed (%s); running eagerly\n" % exc)
+            self._graph = False
+            torch.cuda.set_stream(self.e.tstream)
+
     def _allreduce_async(self, t):
-        if self.G == 1:
+        if self.G == 1 and not self.force_coll:
             return
         if self.staged:
             c = t.cpu()

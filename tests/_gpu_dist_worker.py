@@ -57,6 +57,7 @@ def main():
     except SystemExit as e:
         out["exit"] = int(e.code)
     out["events"] = [list(e) for e in cg.events]
+    out["graph"] = bool(cg._graph)
     sys.stdout.flush()
     if rank == 0:
         print("RESULT " + json.dumps(out))

@@ -26,16 +26,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 WORKER = os.path.join(HERE, "_gpu_dist_worker.py")
 
 
-def run_job(backend, world, matrix, mode, flip, fixed=0):
+def run_job(backend, world, matrix, mode, flip, fixed=0, env=None):
     idx, bit = flip if flip else (-1, 0)
     last = None
+    env = dict(os.environ, **(env or {}))
     for attempt in range(2):
         s = socket.socket()
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
         s.close()
         procs = [subprocess.Popen([sys.executable, WORKER, backend, str(r), str(world), matrix, mode, str(idx),
-                                   str(bit), str(port), str(fixed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+                                   str(bit), str(port), str(fixed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                  env=env)
                  for r in range(world)]
         outs = []
         try:
@@ -123,3 +125,15 @@ def test_fixed_iteration_loop_with_device_scalars(backend, world, matrix):
     assert abs(out["hist"][-1] - hist_o[-1]) <= 1e-10 * hist_o[-1]
     assert np.abs(np.array(out["x"]) - x_o).max() <= 1e-10 * np.abs(x_o).max()
     assert [tuple(e) for e in out["events"]] == [(2, flip[0], flip[1])]
+
+
+@pytest.mark.parametrize("matrix", ["laplace", "random"])
+def test_graph_replay_equals_eager_enqueue(matrix):
+    """run_fixed replays a captured hipGraph per iteration (kernels + RCCL calls, here
+    forced on at world size 1): bit-identical to enqueueing the same calls eagerly."""
+    force = {"ABFT_FORCE_COLLECTIVES": "1"}
+    a, _, ca = run_job("nccl", 1, matrix, "secded", None, fixed=15, env=dict(force, ABFT_CG_GRAPH="1"))
+    b, _, cb = run_job("nccl", 1, matrix, "secded", None, fixed=15, env=dict(force, ABFT_CG_GRAPH="0"))
+    assert ca == cb == [0]
+    assert a["graph"] is True and b["graph"] is False
+    assert a["hist"] == b["hist"] and a["x"] == b["x"]
