@@ -128,16 +128,33 @@ __device__ __forceinline__ uint32_t ecc_suspect(const uint32_t *w) {
   return 0;
 }
 
+// One step of a cross-lane reduction on the DPP path (the operand is permuted
+// inside the VALU, nothing goes through LDS): lanes whose source is out of range
+// or whose row is masked off read 0.0.  __shfl_down on a double compiles to two
+// ds_bpermute_b32 + a wait per step; six dependent steps of that in an epilogue
+// kept every SpMV workgroup alive ~0.3 us longer.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+// sum over the 64 lanes in a fixed tree; the total is valid in LANE 63 only
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  v += dpp_f64<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_f64<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_f64<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_f64<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each 16-lane row holds the row's sum
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds all 64
   return v;
 }
 
 // fixed-shape block reduction (256 threads = 4 waves); every thread gets the sum
 __device__ __forceinline__ double block_sum(double v, double *s_w) {
   v = wave_sum(v);
-  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = v;
   __syncthreads();
   return (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
 }
@@ -211,7 +228,7 @@ __global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t
     for (int k = 0; k < 16; k += 4) acc += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = acc;
+  if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     double tot = 0.0;
