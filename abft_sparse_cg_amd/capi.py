@@ -78,6 +78,7 @@ SIGNATURES = {
     "abft_format_event": (C.c_int, [C.POINTER(Event), C.c_char_p, C.c_size_t]),
     "abft_event_is_fatal": (C.c_int, [C.c_uint32]),
     "abft_hip_profile_enable": (C.c_int, [vp, C.c_int]),
+    "abft_hip_profile_stride": (C.c_int, [vp, C.c_int]),
     "abft_hip_profile_reset": (C.c_int, [vp]),
     "abft_hip_profile_read": (C.c_int, [vp, C.c_int, f64p, C.POINTER(C.c_long)]),
     "abft_hip_stream_probe": (C.c_int, [vp, C.c_size_t, C.c_int, f64p, f64p]),

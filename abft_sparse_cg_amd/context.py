@@ -225,9 +225,11 @@ class HIPContext:
             raise FatalEvent(events)
 
     # ---- measurement ------------------------------------------------------
-    def profile(self, mask=0xF):
-        """bit k of mask brackets kernel k (capi.K_*) with HIP events; 0 = off"""
+    def profile(self, mask=0xF, stride=1):
+        """bit k of mask brackets kernel k (capi.K_*) with HIP events, every
+        `stride`-th launch of it; 0 = off"""
         self.prof_mask = 0xF if mask is True else int(mask)
+        check(self.L.abft_hip_profile_stride(self.h, stride))
         check(self.L.abft_hip_profile_enable(self.h, self.prof_mask))
         check(self.L.abft_hip_profile_reset(self.h))
 

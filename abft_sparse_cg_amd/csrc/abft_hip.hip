@@ -65,6 +65,7 @@ struct abft_hip_ctx {
     double value = 0.0;
   } fused;
   unsigned prof = 0;  // bit k: bracket launches of kernel k with HIP events
+  unsigned prof_stride = 1, prof_seen[ABFT_K_COUNT] = {};  // ... every prof_stride-th launch of it
   ProfSlot prof_k[ABFT_K_COUNT];
   std::vector<hipEvent_t> ev_pool;
 };
@@ -106,6 +107,7 @@ struct KernelTimer {
   hipEvent_t a = nullptr, b = nullptr;
   KernelTimer(abft_hip_ctx *c, int k) : ctx(c), id(k) {
     if (!(ctx->prof >> id & 1u)) return;
+    if (ctx->prof_seen[id]++ % ctx->prof_stride) return;
     a = take();
     b = take();
     if (a && b) (void)hipEventRecord(a, ctx->stream);
@@ -968,6 +970,14 @@ extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap
 extern "C" int abft_hip_profile_enable(abft_hip_ctx *ctx, int on) {
   if (int rc = bind(ctx)) return rc;
   ctx->prof = on < 0 ? 0u : (unsigned)on & ((1u << ABFT_K_COUNT) - 1u);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_profile_stride(abft_hip_ctx *ctx, int stride) {
+  if (int rc = bind(ctx)) return rc;
+  if (stride < 1) return set_err(ABFT_ERR_INVALID, "profile stride %d", stride);
+  ctx->prof_stride = (unsigned)stride;
+  for (unsigned &n : ctx->prof_seen) n = 0;
   return ABFT_OK;
 }
 

@@ -226,8 +226,10 @@ typedef enum {
  * interest enabled.  abft_hip_profile_read synchronises and returns the summed
  * device time (ms) and launch count since the last reset.  With the fused dot
  * (spmv on a square matrix), ABFT_K_DOT times the one-block fold that is left
- * of dot(p, w). */
+ * of dot(p, w).  abft_hip_profile_stride(n) brackets only every n-th launch of an
+ * enabled kernel (default 1): a sampled average at 1/n of the cost. */
 int abft_hip_profile_enable(abft_hip_ctx *ctx, int mask);
+int abft_hip_profile_stride(abft_hip_ctx *ctx, int stride);
 int abft_hip_profile_reset(abft_hip_ctx *ctx);
 int abft_hip_profile_read(abft_hip_ctx *ctx, int kernel, double *total_ms, long *launches);
 
