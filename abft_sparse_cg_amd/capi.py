@@ -17,6 +17,7 @@ MODE_ID = {m: i for i, m in enumerate(MODES)}
 MODE_ID["sec"] = MODE_ID["sec7"]  # BASELINE.json config 5 spells sec7 "sec"
 FMT_CSR, FMT_COO = 0, 1
 FLIP_ANY, FLIP_VALUE, FLIP_INDEX = 0, 1, 2
+PART_ALL, PART_INTERIOR, PART_BOUNDARY = 0, 1, 2
 K_SPMV, K_DOT, K_CALC_XR, K_CALC_P = 0, 1, 2, 3
 
 u32p = C.POINTER(C.c_uint32)
@@ -71,6 +72,9 @@ SIGNATURES = {
     "abft_hip_dot_dev": (C.c_int, [vp, vp, vp, vp]),
     "abft_hip_calc_xr_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_double, vp]),
     "abft_hip_spmv_dot_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
+    "abft_hip_matrix_set_interior": (C.c_int, [vp, C.c_int, C.c_int]),
+    "abft_hip_spmv_part": (C.c_int, [vp, vp, vp, vp, C.c_int]),
+    "abft_hip_spmv_dot_part_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int]),
     "abft_hip_calc_xr_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "abft_hip_calc_p_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp]),
     "abft_hip_drain_events": (C.c_int, [vp, C.POINTER(Event), C.c_int, i32p, i32p]),

@@ -170,8 +170,15 @@ class HIPContext:
     def calc_p(self, p, r, beta):
         check(self.L.abft_hip_calc_p(self.h, p.h, r.h, beta))
 
-    def spmv(self, mat, vec, result):
-        check(self.L.abft_hip_spmv(self.h, mat.h, vec.h, result.h))
+    def spmv(self, mat, vec, result, part=capi.PART_ALL):
+        if part == capi.PART_ALL:
+            check(self.L.abft_hip_spmv(self.h, mat.h, vec.h, result.h))
+        else:
+            check(self.L.abft_hip_spmv_part(self.h, mat.h, vec.h, result.h, part))
+
+    def set_interior(self, mat, row_lo, row_hi):
+        """rows [row_lo, row_hi) read nothing a peer still has to send (include/abft_hip.h)"""
+        check(self.L.abft_hip_matrix_set_interior(mat.h, row_lo, row_hi))
 
     def inject_bitflip(self, mat, kind, num_flips):
         """reference CSR/CPUContext.cpp:135-159 / COO/CPUContext.cpp:123-140: the

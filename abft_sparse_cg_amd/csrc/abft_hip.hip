@@ -80,6 +80,10 @@ struct abft_hip_matrix {
   CsrPanels panels{};
   uint32_t panel_grid = 0;          // workgroups of the panel kernel
   uint32_t panel_chunk = 0;         // panels per launch (0 = all)
+  // streaming CSR: host copy of the row-block descriptors, and the tiles [t_lo, t_hi)
+  // made of interior rows only (abft_hip_matrix_set_interior; empty by default)
+  std::vector<uint4> blk_host;
+  uint32_t t_lo = 0, t_hi = 0;
   std::vector<void *> allocs;
 };
 
@@ -415,6 +419,7 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   }
   A.rowptr = d_rowptr;
   A.blk = d_blk;
+  if (!panels) m->blk_host = blk;
   hipError_t e = launch_encode_csr(mode, A.cols, A.vals, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host arrays may be freed on return
   if (e != hipSuccess) {
@@ -552,6 +557,23 @@ extern "C" int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int m
                                             const double *values, int n_out, int n_in, int nnz,
                                             uint32_t index_base, abft_hip_matrix **mat) {
   return create_any(ctx, format, mode, columns, rows, values, n_out, n_in, nnz, index_base, mat);
+}
+
+extern "C" int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, int row_hi) {
+  if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
+  const int n_out = mat->fmt == ABFT_FMT_CSR ? (int)mat->csr.n_out : (int)mat->coo.n_out;
+  if (row_lo < 0 || row_hi < row_lo || row_hi > n_out)
+    return set_err(ABFT_ERR_INVALID, "interior rows [%d,%d) outside [0,%d)", row_lo, row_hi, n_out);
+  mat->t_lo = mat->t_hi = 0;
+  // only the streaming CSR layout launches by row block; elsewhere the interior
+  // part stays empty and ABFT_PART_BOUNDARY does all the work
+  const std::vector<uint4> &b = mat->blk_host;
+  uint32_t lo = 0;
+  while (lo < b.size() && b[lo].x < (uint32_t)row_lo) lo++;  // first tile starting at or after row_lo
+  uint32_t hi = lo;
+  while (hi < b.size() && b[hi].y <= (uint32_t)row_hi) hi++;  // tiles that end at or before row_hi
+  if (hi > lo) { mat->t_lo = lo; mat->t_hi = hi; }
+  return ABFT_OK;
 }
 
 extern "C" int abft_hip_matrix_destroy(abft_hip_matrix *mat) {
@@ -836,9 +858,10 @@ extern "C" int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, 
 // Shared by abft_hip_spmv (dev_pair == nullptr: the fused product, if any, goes to
 // the pinned slot for a following dot) and abft_hip_spmv_dot_dev.
 static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
-                       abft_hip_vector *result, int vec_offset, double *dev_pair) {
+                       abft_hip_vector *result, int vec_offset, double *dev_pair, int part = ABFT_PART_ALL) {
   if (int rc = bind(ctx)) return rc;
   if (!mat || !vec || !result) return set_err(ABFT_ERR_INVALID, "spmv: null argument");
+  if (part < ABFT_PART_ALL || part > ABFT_PART_BOUNDARY) return set_err(ABFT_ERR_INVALID, "spmv: unknown part %d", part);
   const uint32_t n_out = mat->fmt == ABFT_FMT_CSR ? mat->csr.n_out : mat->coo.n_out;
   const uint32_t n_in = mat->fmt == ABFT_FMT_CSR ? mat->csr.n_in : mat->coo.n_in;
   // the kernels index vec with [0,n_in) and result with [0,n_out): check here, on the host
@@ -855,6 +878,12 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
                        (uint32_t)result->n == n_out;
   const bool do_fuse = mat->fuse_partials && (dev_pair || to_host);
   if (dev_pair && !do_fuse) return set_err(ABFT_ERR_INVALID, "spmv_dot: matrix has no rows");
+  // tiles of this call (streaming CSR only; other layouts have no interior part)
+  const uint32_t n_int = mat->t_hi - mat->t_lo;
+  if (part == ABFT_PART_INTERIOR && n_int == 0) return ABFT_OK;  // nothing to run ahead of the exchange
+  TileSpan span{0u, mat->csr.nblk, 0u, mat->csr.nblk};
+  if (part == ABFT_PART_INTERIOR) span = TileSpan{mat->t_lo, n_int, 0u, n_int};
+  else if (part == ABFT_PART_BOUNDARY && n_int) span = TileSpan{0u, mat->t_lo, n_int, mat->csr.nblk - n_int};
   if (do_fuse) {
     fuse.partials = mat->fuse_partials;
     fuse.host = dev_pair ? nullptr : ctx->host_slot_dev;
@@ -875,10 +904,12 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
       HIPCHK(launch_spmv_coo_panels(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
                                     do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
     } else if (mat->fmt == ABFT_FMT_CSR)
-      HIPCHK(launch_spmv_csr(mat->mode, mat->csr, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
+      HIPCHK(launch_spmv_csr(mat->mode, mat->csr, span, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr,
+                             ctx->stream));
     else
       HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
   }
+  if (part == ABFT_PART_INTERIOR) return ABFT_OK;  // the boundary call folds and publishes
   if (do_fuse) {
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
     HIPCHK(launch_fuse_finalize(fuse, nparts, ctx->stream));
@@ -903,6 +934,17 @@ extern "C" int abft_hip_spmv_dot_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, co
                                      abft_hip_vector *result, int vec_offset, double *dev_result) {
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
   return spmv_common(ctx, mat, vec, result, vec_offset, dev_result);
+}
+
+extern "C" int abft_hip_spmv_part(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                                  abft_hip_vector *result, int part) {
+  return spmv_common(ctx, mat, vec, result, 0, nullptr, part);
+}
+
+extern "C" int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                                          abft_hip_vector *result, int vec_offset, double *dev_result, int part) {
+  if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
+  return spmv_common(ctx, mat, vec, result, vec_offset, dev_result, part);
 }
 
 // ------------------------------------------------------------------- events --

@@ -134,6 +134,14 @@ struct FuseOut {
   uint32_t x_off;    // the product uses vec[x_off + row] (a shard's slot in the gathered vector)
 };
 
+// Which row blocks (tiles) of a streaming-layout CSR matrix one launch covers:
+// workgroup b takes tile first + b, plus `skip` once b >= cut.  Whole matrix:
+// {0, nblk, 0, nblk}; interior rows of a shard: {t_lo, n, 0, n}; the rest:
+// {0, t_lo, t_hi - t_lo, nblk - (t_hi - t_lo)}.
+struct TileSpan {
+  uint32_t first, cut, skip, count;
+};
+
 // panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
 hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,
                                   EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
@@ -144,7 +152,7 @@ hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P,
                                   hipStream_t s);
 // fuse == nullptr: plain SpMV; otherwise follow with launch_fuse_finalize
 hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s);
-hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,
+hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);
 hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);

@@ -207,10 +207,10 @@ hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s
 // block resident ~2x longer and cost 75 us per SpMV.)  fuse_finalize_kernel,
 // launched behind the SpMV on the same stream, folds the partials in a fixed
 // order and publishes the scalar.
-__device__ __forceinline__ void fused_dot_finish(double dsum, const FuseOut &f) {
+__device__ __forceinline__ void fused_dot_finish(double dsum, const FuseOut &f, uint32_t slot) {
   __shared__ double s_w[4];
   const double bsum = block_sum(dsum, s_w);
-  if (threadIdx.x == 0) f.partials[blockIdx.x] = bsum;
+  if (threadIdx.x == 0) f.partials[slot] = bsum;
 }
 
 __global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t nblk) {
@@ -411,11 +411,12 @@ __device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev
 template <int MODE, int EPT, bool FUSE>
 __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const double *__restrict__ x,
                                                               double *__restrict__ y, EventRing ev,
-                                                              FuseOut fuse) {
+                                                              FuseOut fuse, TileSpan span) {
   constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[MODE == MODE_CONSTRAINTS ? TILE : 2];
-  const uint32_t t = xcd_tile(blockIdx.x, A.nblk);
+  const uint32_t b = xcd_tile(blockIdx.x, span.count);
+  const uint32_t t = span.first + b + (b >= span.cut ? span.skip : 0u);
   const uint4 desc = A.blk[t];  // one scalar load instead of two dependent pairs
   const uint32_t row0 = desc.x, row1 = desc.y, e0 = desc.z, e1 = desc.w;
   const uint32_t base = e0 & ~1u;
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
       }
     }
   }
-  if (FUSE) fused_dot_finish(dsum, fuse);
+  if (FUSE) fused_dot_finish(dsum, fuse, t);
 }
 
 // Panel-layout CSR SpMV (see CsrPanels).  Persistent workgroups: each takes row
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
       }
     }
   }
-  if (FUSE) fused_dot_finish(dsum, fuse);
+  if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
 }
 
 template <int MODE>
@@ -602,27 +603,29 @@ int spmv_csr_panels_blocks_per_cu(int mode, bool fuse) {
 }
 
 template <int MODE>
-static hipError_t launch_spmv_csr_mode(const CsrDev &A, const double *x, double *y, EventRing ev,
-                                       const FuseOut *fuse, hipStream_t s) {
+static hipError_t launch_spmv_csr_mode(const CsrDev &A, const TileSpan &span, const double *x, double *y,
+                                       EventRing ev, const FuseOut *fuse, hipStream_t s) {
   if (fuse) {
-    hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT, true>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
-                       x, y, ev, *fuse);
+    hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT, true>), dim3(span.count), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, *fuse, span);
   } else
-    hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT, false>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
-                       x, y, ev, FuseOut{});
+    hipLaunchKernelGGL((spmv_csr_kernel<MODE, ABFT_CSR_EPT, false>), dim3(span.count), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, FuseOut{}, span);
   return hipGetLastError();
 }
 
-hipError_t launch_spmv_csr(int mode, const CsrDev &A, const double *x, double *y, EventRing ev,
-                           const FuseOut *fuse, hipStream_t s) {
-  if (A.nblk == 0) return hipSuccess;
+hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, const double *x, double *y,
+                           EventRing ev, const FuseOut *fuse, hipStream_t s) {
+  // every tile the span maps to must exist: checked here, on the host
+  if (span.count == 0) return hipSuccess;
+  if ((uint64_t)span.first + span.count + span.skip > A.nblk || span.cut > span.count) return hipErrorInvalidValue;
   switch (mode) {
-    case MODE_NONE: return launch_spmv_csr_mode<MODE_NONE>(A, x, y, ev, fuse, s);
-    case MODE_CONSTRAINTS: return launch_spmv_csr_mode<MODE_CONSTRAINTS>(A, x, y, ev, fuse, s);
-    case MODE_SED: return launch_spmv_csr_mode<MODE_SED>(A, x, y, ev, fuse, s);
-    case MODE_SEC7: return launch_spmv_csr_mode<MODE_SEC7>(A, x, y, ev, fuse, s);
-    case MODE_SEC8: return launch_spmv_csr_mode<MODE_SEC8>(A, x, y, ev, fuse, s);
-    case MODE_SECDED: return launch_spmv_csr_mode<MODE_SECDED>(A, x, y, ev, fuse, s);
+    case MODE_NONE: return launch_spmv_csr_mode<MODE_NONE>(A, span, x, y, ev, fuse, s);
+    case MODE_CONSTRAINTS: return launch_spmv_csr_mode<MODE_CONSTRAINTS>(A, span, x, y, ev, fuse, s);
+    case MODE_SED: return launch_spmv_csr_mode<MODE_SED>(A, span, x, y, ev, fuse, s);
+    case MODE_SEC7: return launch_spmv_csr_mode<MODE_SEC7>(A, span, x, y, ev, fuse, s);
+    case MODE_SEC8: return launch_spmv_csr_mode<MODE_SEC8>(A, span, x, y, ev, fuse, s);
+    case MODE_SECDED: return launch_spmv_csr_mode<MODE_SECDED>(A, span, x, y, ev, fuse, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
       }
     }
   }
-  if (FUSE) fused_dot_finish(dsum, fuse);
+  if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
 }
 
 // continue an ordered sum over LDS slots [a, b) from `acc` (see lds_ordered_sum)
@@ -835,7 +838,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
       }
     }
   }
-  if (FUSE) fused_dot_finish(dsum, fuse);
+  if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
 }
 
 template <int MODE>

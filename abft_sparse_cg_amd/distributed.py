@@ -82,8 +82,11 @@ class HipEngine:
     def copy(self, dst, src):
         self.ctx.copy_vector(dst, src)
 
-    def spmv(self, A, x, y):
-        self.ctx.spmv(A, x, y)
+    def spmv(self, A, x, y, part=capi.PART_ALL):
+        self.ctx.spmv(A, x, y, part)
+
+    def set_interior(self, A, row_lo, row_hi):
+        self.ctx.set_interior(A, row_lo, row_hi)
 
     def dot_partial(self, a, b, out):
         capi.check(self.L.abft_hip_dot_dev(self.ctx.h, a.h, b.h, out.device_ptr))
@@ -95,8 +98,8 @@ class HipEngine:
         self.ctx.calc_p(p, r, beta)
 
     # device-scalar forms (include/abft_hip.h): nothing comes back to the host
-    def spmv_dot(self, A, x, x_off, y, out):
-        capi.check(self.L.abft_hip_spmv_dot_dev(self.ctx.h, A.h, x.h, y.h, x_off, out.device_ptr))
+    def spmv_dot(self, A, x, x_off, y, out, part=capi.PART_ALL):
+        capi.check(self.L.abft_hip_spmv_dot_part_dev(self.ctx.h, A.h, x.h, y.h, x_off, out.device_ptr, part))
 
     def calc_xr_ratio(self, x, r, p, w, num, den, out):
         capi.check(self.L.abft_hip_calc_xr_ratio_dev(self.ctx.h, x.h, r.h, p.h, w.h, num.device_ptr, den.device_ptr,
@@ -165,6 +168,18 @@ class ShardedCG:
             pcols, owner = pad_columns(cols, self.bounds, self.slot)
         lrows = (np.asarray(rows).astype(np.int64) - self.r0).astype(np.uint32)
         self.A = engine.create_matrix(pcols, lrows, vals, self.n_loc, self.n_pad, nnz_before)
+        # Rows that read only this rank's own slot can be multiplied while the exchange
+        # is in flight: take the longest run of consecutive such rows (for a banded
+        # matrix: everything but the first and last few rows of the shard).  Row sums
+        # are never split, so the result stays bit-identical.
+        self.interior = None
+        if self.G > 1 and self.n_loc:
+            edge = np.concatenate(([-1], np.unique(lrows[owner != self.rank]).astype(np.int64), [self.n_loc]))
+            k = int(np.argmax(np.diff(edge)))
+            lo, hi = int(edge[k]) + 1, int(edge[k + 1])
+            if hi - lo >= self.n_loc // 4:
+                self.interior = (lo, hi)
+                engine.set_interior(self.A, lo, hi)
         # which window of each peer's slot this rank reads
         need = []
         for g in range(self.G):
@@ -200,39 +215,62 @@ class ShardedCG:
     # ---- collectives -------------------------------------------------------
     def exchange(self, full_vec_tensor):
         """Fill the peers' slots of a gathered buffer whose own slot is current."""
+        self.exchange_finish(self.exchange_begin(full_vec_tensor))
+
+    def exchange_begin(self, full_vec_tensor):
+        """Start the exchange and return a handle for exchange_finish.  Work that
+        reads only this rank's own slot may be enqueued in between: the collective
+        runs on the backend's stream beside it.  (Host-staged collectives are
+        synchronous: there the whole exchange happens in exchange_finish, i.e.
+        strictly after whatever was enqueued in between.)"""
         if self.G == 1 and not self.force_coll:
-            return
-        S, me = self.slot, self.rank
+            return None
         if self.staged:
-            dev_tensor, full_vec_tensor = full_vec_tensor, full_vec_tensor.cpu()
+            return ("staged", full_vec_tensor)
+        S, me = self.slot, self.rank
         if not self.use_windows:
-            dist.all_gather_into_tensor(full_vec_tensor, full_vec_tensor[me * S:(me + 1) * S].clone()
-                                        if self.staged else full_vec_tensor[me * S:(me + 1) * S], group=self.group)
-            if self.staged:
-                dev_tensor.copy_(full_vec_tensor)
+            return [dist.all_gather_into_tensor(full_vec_tensor, full_vec_tensor[me * S:(me + 1) * S],
+                                                group=self.group, async_op=True)]
+        ops = self._window_ops(full_vec_tensor, full_vec_tensor.data_ptr())
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def exchange_finish(self, handle):
+        if handle is None:
             return
-        key = None if self.staged else full_vec_tensor.data_ptr()
-        ops = self._p2p_cache.get(key)
+        if isinstance(handle, tuple):  # host-staged
+            dev_tensor = handle[1]
+            host = dev_tensor.cpu()
+            S, me = self.slot, self.rank
+            if not self.use_windows:
+                dist.all_gather_into_tensor(host, host[me * S:(me + 1) * S].clone(), group=self.group)
+            else:
+                ops = self._window_ops(host, None)
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+            dev_tensor.copy_(host)
+            return
+        for req in handle:
+            req.wait()
+
+    def _window_ops(self, t, key):
+        """point-to-point copies of the windows each rank reads of its peers' slots"""
+        ops = self._p2p_cache.get(key) if key is not None else None
         if ops is None:  # the windows are fixed for the life of the solver: build the op list once per buffer
+            S, me = self.slot, self.rank
             ops = []
             for g in range(self.G):
                 if g == me:
                     continue
                 lo, hi = self.all_need[g][me]  # what peer g reads from my slot
                 if hi > lo:
-                    ops.append(dist.P2POp(dist.isend, full_vec_tensor[me * S + lo:me * S + hi], self._peer(g),
-                                          self.group))
+                    ops.append(dist.P2POp(dist.isend, t[me * S + lo:me * S + hi], self._peer(g), self.group))
                 lo, hi = self.need[g]
                 if hi > lo:
-                    ops.append(dist.P2POp(dist.irecv, full_vec_tensor[g * S + lo:g * S + hi], self._peer(g),
-                                          self.group))
+                    ops.append(dist.P2POp(dist.irecv, t[g * S + lo:g * S + hi], self._peer(g), self.group))
             if key is not None:
                 self._p2p_cache[key] = ops
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        if self.staged:
-            dev_tensor.copy_(full_vec_tensor)
+        return ops
 
     def _peer(self, g):
         return dist.get_global_rank(self.group, g) if self.group is not None else g
@@ -288,8 +326,10 @@ class ShardedCG:
 
     def step(self):
         """One CG iteration, cg.cpp:97-114, with the exchange in front of the SpMV."""
-        self.exchange(self.t_full)
-        self.e.spmv(self.A, self.p_full, self.w)
+        h = self.exchange_begin(self.t_full)
+        self.e.spmv(self.A, self.p_full, self.w, capi.PART_INTERIOR)  # rows that need no peer data
+        self.exchange_finish(h)
+        self.e.spmv(self.A, self.p_full, self.w, capi.PART_BOUNDARY)
         pw = self.dot(self.p, self.w)
         alpha = self.rr / pw
         self.e.calc_xr_partial(self.x, self.r, self.p, self.w, alpha, self.scal)
@@ -314,7 +354,8 @@ class ShardedCG:
         exchange -- is captured once into a hipGraph on the shared stream (two graphs:
         the rr / rr_new scalars swap roles every iteration) and replayed, so the host
         issues one launch per iteration instead of ~8 calls.  Point-to-point window
-        copies stay outside the graph and are issued eagerly between replays.  The
+        copies stay outside the graph and are issued eagerly between replays (the
+        interior rows' SpMV is replayed between their start and their completion).  The
         first two iterations of the first call run eagerly (communicators and peer
         connections are set up by their first use, which must not happen under
         capture); if capture is refused the loop carries on eagerly.
@@ -342,9 +383,7 @@ class ShardedCG:
             self._capture(s0, s1, pw)
         if graph and self._graph:
             while left:
-                if self.use_windows:
-                    self.exchange(self.t_full)
-                self._graph[k & 1].replay()
+                self._replay(k)
                 k += 1
                 left -= 1
         pair = (s0, s1)
@@ -359,29 +398,52 @@ class ShardedCG:
             raise SystemExit(1)
         return self.rr
 
-    def _iteration(self, cur, nxt, pw, exchange=True):
+    def _iteration(self, cur, nxt, pw):
         """enqueue one iteration: rr in cur -> rr_new in nxt"""
-        if exchange:
-            self.exchange(self.t_full)
-        self.e.spmv_dot(self.A, self.p_full, self.rank * self.slot, self.w, pw[0])
+        h = self.exchange_begin(self.t_full)
+        self._interior_part(pw)
+        self.exchange_finish(h)
+        self._rest(cur, nxt, pw)
+
+    def _interior_part(self, pw):
+        # rows that read nothing from the peers: beside the exchange, not behind it
+        self.e.spmv_dot(self.A, self.p_full, self.rank * self.slot, self.w, pw[0], capi.PART_INTERIOR)
+
+    def _rest(self, cur, nxt, pw):
+        self.e.spmv_dot(self.A, self.p_full, self.rank * self.slot, self.w, pw[0], capi.PART_BOUNDARY)
         self._allreduce_async(pw[1])
         self.e.calc_xr_ratio(self.x, self.r, self.p, self.w, cur[0], pw[0], nxt[0])
         self._allreduce_async(nxt[1])
         self.e.calc_p_ratio(self.p, self.r, nxt[0], cur[0])
 
     def _capture(self, s0, s1, pw):
-        graphs = []
+        """all-gather mode: one graph per parity holding the whole iteration;
+        window mode: the point-to-point copies stay eager, so the iteration is cut
+        at them into an interior graph and, per parity, a graph of the rest"""
+        def record(fn, *args):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.e.tstream, capture_error_mode="thread_local"):
+                fn(*args)
+            return g
         try:
-            for cur, nxt in ((s0, s1), (s1, s0)):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self.e.tstream, capture_error_mode="thread_local"):
-                    self._iteration(cur, nxt, pw, exchange=not self.use_windows)
-                graphs.append(g)
-            self._graph = graphs
+            if self.use_windows:
+                gi = record(self._interior_part, pw) if self.interior else None
+                self._graph = (gi, [record(self._rest, s0, s1, pw), record(self._rest, s1, s0, pw)])
+            else:
+                self._graph = (None, [record(self._iteration, s0, s1, pw), record(self._iteration, s1, s0, pw)])
         except Exception as exc:  # capture refused: keep going without it
             sys.stderr.write("abft: hipGraph capture of the CG iteration failed (%s); running eagerly\n" % exc)
             self._graph = False
             torch.cuda.set_stream(self.e.tstream)
+
+    def _replay(self, k):
+        gi, rest = self._graph
+        if self.use_windows:
+            h = self.exchange_begin(self.t_full)
+            if gi is not None:
+                gi.replay()
+            self.exchange_finish(h)
+        rest[k & 1].replay()
 
     def _allreduce_async(self, t):
         if self.G == 1 and not self.force_coll:

@@ -197,6 +197,24 @@ int abft_hip_calc_xr_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_v
 int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r,
                               const double *dev_num, const double *dev_den);
 
+/* SpMV in two parts, so a shard can multiply the rows that need nothing from its
+ * peers while the exchange of the input vector is still in flight.
+ * abft_hip_matrix_set_interior declares rows [row_lo, row_hi) of the matrix
+ * "interior": every input entry they read is in place before the exchange.  Then
+ *   part = ABFT_PART_INTERIOR   multiplies (whole row blocks of) those rows only,
+ *   part = ABFT_PART_BOUNDARY   all the others, and completes the fused product;
+ * issued in that order on unchanged vectors, the two calls together equal one
+ * ABFT_PART_ALL call bit for bit, events included.  Row sums are never split
+ * (an output's additions keep the reference's order), so this is a split by
+ * rows, not by columns.  Layouts without row-block launches (panels, COO) keep
+ * the interior part empty: INTERIOR returns at once and BOUNDARY does the work. */
+typedef enum { ABFT_PART_ALL = 0, ABFT_PART_INTERIOR = 1, ABFT_PART_BOUNDARY = 2 } abft_part;
+int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, int row_hi);
+int abft_hip_spmv_part(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                       abft_hip_vector *result, int part);
+int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                               abft_hip_vector *result, int vec_offset, double *dev_result, int part);
+
 /* ---- events ------------------------------------------------------------ */
 
 /* Synchronise, then move the queued events to `buf` (at most `cap`), sorted

@@ -63,8 +63,29 @@ class OracleEngine:
     def copy(self, dst, src):
         dst.a[:] = src.a[:dst.N]
 
-    def spmv(self, A, x, y):
-        self.L.ora_spmv(A.h, _p(x.a, f64p), _p(y.a, f64p), 1)
+    def set_interior(self, A, lo, hi):
+        A.interior = (lo, hi)
+
+    def spmv(self, A, x, y, part=0):
+        """part 1 (interior) runs BEFORE the peers' data is known to have arrived, part
+        2 (boundary) after: the interior rows computed early must equal, bit for bit,
+        what a full SpMV gives once everything is in place -- i.e. the rows the
+        solver declared interior really read nothing from a peer."""
+        lo, hi = getattr(A, "interior", (0, 0))
+        if part == 1 and hi <= lo:
+            return
+        tmp = np.empty_like(y.a)
+        self.L.ora_spmv(A.h, _p(x.a, f64p), _p(tmp, f64p), 1)
+        if part == 1:
+            y.a[lo:hi] = tmp[lo:hi]
+            A.early = True
+            return
+        if part == 2 and hi > lo:
+            assert getattr(A, "early", False), "boundary part without the interior part before it"
+            assert np.array_equal(tmp[lo:hi].view(np.uint64), y.a[lo:hi].view(np.uint64)), \
+                "an interior row changed when the peers' data arrived"
+            A.early = False
+        y.a[:] = tmp
 
     def dot_partial(self, a, b, out):
         out.a[0] = self.L.ora_dot(_p(a.a, f64p), _p(b.a, f64p), a.N)
@@ -77,8 +98,10 @@ class OracleEngine:
     def calc_p(self, p, r, beta):
         self.L.ora_calc_p(_p(p.a, f64p), _p(r.a, f64p), beta, p.N)
 
-    def spmv_dot(self, A, x, x_off, y, out):
-        self.spmv(A, x, y)
+    def spmv_dot(self, A, x, x_off, y, out, part=0):
+        self.spmv(A, x, y, part)
+        if part == 1:
+            return
         xs = np.ascontiguousarray(x.a[x_off:x_off + y.N])
         out.a[0] = self.L.ora_dot(_p(xs, f64p), _p(y.a, f64p), y.N)
         out.a[1] = self._peek()
@@ -152,7 +175,7 @@ def _worker(rank, world, port, case, q):
         except SystemExit as e:
             code, it, x, tot, mx = int(e.code), len(hist), None, None, None
         if rank == 0:
-            q.put((code, it, hist, x, tot, mx, cg.events, cg.use_windows))
+            q.put((code, it, hist, x, tot, mx, cg.events, (cg.use_windows, cg.interior)))
     finally:
         dist.destroy_process_group()
 
@@ -201,7 +224,14 @@ def test_sharded_cg_matches_single_process(world, matrix):
     assert np.allclose(hist, hist_s, rtol=1e-10, atol=0)
     assert np.abs(x - x_s).max() <= 1e-10 * np.abs(x_s).max()
     assert events == []
+    windows, interior = windows
     assert windows == (matrix == "laplace")  # banded: halo windows; scattered: all-gather
+    # banded: all rows but the first / last grid line of the shard run beside the exchange
+    if matrix == "laplace":
+        r0, r1 = bounds[0], bounds[1]
+        assert interior == (0, r1 - r0 - 24)  # rank 0 has no lower neighbour
+    else:
+        assert interior is None
     # cg.cpp:131-144 error report, against a dense recomputation
     import scipy.sparse as sp
     A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
@@ -237,11 +267,11 @@ def test_pad_columns_layout():
     assert list(p) == [0, 2, 7, 13, 14, 15]
 
 
-@pytest.mark.parametrize("world", [1, 2, 3])
-def test_fixed_iteration_loop_with_device_scalars(world):
+@pytest.mark.parametrize("world,matrix", [(1, "random"), (2, "random"), (3, "random"), (2, "laplace"), (3, "laplace")])
+def test_fixed_iteration_loop_with_device_scalars(world, matrix):
     """run_fixed (alpha, beta formed on the device, nothing read back per iteration)
     walks the same iterates as the reference loop."""
-    cols, rows, vals, n = random_spd(300, 8, seed=3)
+    cols, rows, vals, n = random_spd(300, 8, seed=3) if matrix == "random" else laplace5(24, 24)
     bounds = uneven_bounds(rows, n, world)
     iters = 12
     o = OracleMatrix(CSR, "none", cols, rows, vals, n)

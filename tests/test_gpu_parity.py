@@ -487,3 +487,62 @@ def test_panel_layout_forced_on_small_matrices(amd, fmt, width, chunk, monkeypat
                     assert abs(d - ora_dot(x, y)) <= 1e-13 * float(np.abs(x * y).sum())
             finally:
                 h.close()
+
+
+@pytest.mark.parametrize("mat,lo,hi", [("lap40", 40, 1280), ("ragged", 7, 650), ("lap40", 0, 1320), ("rnd300", 100, 100)])
+@pytest.mark.parametrize("mode", ["none", "secded"])
+def test_spmv_in_two_parts_equals_one_launch(amd, mode, mat, lo, hi):
+    """abft_hip_spmv_part / abft_hip_spmv_dot_part_dev (a shard's rows that need no
+    peer data run beside the exchange): INTERIOR then BOUNDARY = ALL, bit for bit --
+    y, the fused product, and the ECC events (flips on both sides of the split)."""
+    from abft_sparse_cg_amd import capi
+    cols, rows, vals, n = MATS[mat]()
+    x = rhs(n, 4)
+    nnz = len(vals)
+    flips = [(0, 17), (nnz // 2, 70), (nnz - 1, 3)] if mode == "secded" else []
+    seen = []
+    ctx = amd.HIPContext(mode, "csr", on_event=lambda ev, fatal: seen.extend(ev))
+    try:
+        outs = []
+        for split in (False, True):
+            A = ctx.create_matrix(cols, rows, vals, n, nnz)
+            if split:
+                ctx.set_interior(A, lo, hi)
+            for i, b in flips:
+                ctx.inject_at(A, i, [b])
+            vx, vy, sc = ctx.create_vector(n), ctx.create_vector(n), ctx.create_vector(2)
+            ctx.upload(vx, x)
+            ctx.upload(vy, np.full(n, np.nan))
+            L, h = ctx.L, ctx.h
+            if split:
+                # interior rows are written by the first call, everything else still NaN
+                capi.check(L.abft_hip_spmv_dot_part_dev(h, A.h, vx.h, vy.h, 0, sc.device_ptr, capi.PART_INTERIOR))
+                part = ctx.download(vy)
+                capi.check(L.abft_hip_spmv_dot_part_dev(h, A.h, vx.h, vy.h, 0, sc.device_ptr, capi.PART_BOUNDARY))
+            else:
+                capi.check(L.abft_hip_spmv_dot_dev(h, A.h, vx.h, vy.h, 0, sc.device_ptr))
+            y, s = ctx.download(vy), ctx.download(sc)
+            ctx._drain()
+            outs.append((y, s, sorted(seen)))
+            seen.clear()
+            if split:
+                done = ~np.isnan(part)
+                assert not done[:lo].any() and not done[hi:].any()  # never outside the declared rows
+                assert bits_equal(part[done], y[done])
+                # host-scalar form: same two calls through abft_hip_spmv_part
+                ctx.upload(vy, np.full(n, np.nan))
+                ctx.spmv(A, vx, vy, capi.PART_INTERIOR)
+                ctx.spmv(A, vx, vy, capi.PART_BOUNDARY)
+                assert bits_equal(ctx.download(vy), y)
+            ctx.destroy_matrix(A)
+        (y0, s0, e0), (y1, s1, e1) = outs
+        # (s[1], the queued-event count, is lower in the split run only because the
+        # download between its two calls already drained the interior's events)
+        assert bits_equal(y0, y1) and bits_equal(s0[:1], s1[:1]) and e0 == e1
+        assert len(e0) == len(flips)
+        o = OracleMatrix(CSR, mode, cols, rows, vals, n)
+        for i, b in flips:
+            o.inject(i, [b])
+        assert bits_equal(y0, o.spmv(x))
+    finally:
+        ctx.close()
