@@ -164,5 +164,6 @@ hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w
                           const double *num, const double *den, int n, const ReduceOut &out, hipStream_t s);
 hipError_t launch_calc_p(double *p, const double *r, double beta, const double *num, const double *den, int n,
                          hipStream_t s);
+hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s);
 hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s);
 hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s);

@@ -1115,6 +1115,32 @@ hipError_t launch_calc_p(double *p, const double *r, double beta, const double *
   return hipGetLastError();
 }
 
+// copy_vector (reference CSR/CPUContext.cpp:76-80: memcpy of dst->N doubles).  A
+// kernel rather than hipMemcpyAsync: the runtime's device-to-device path took
+// ~1.3 ms per 80 MB vector in the driver's timed loop, this one the 27 us the bytes cost.
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void copy_kernel(double *__restrict__ dst, const double *__restrict__ src,
+                                                          int n) {
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n)
+      *reinterpret_cast<double2 *>(dst + i) = *reinterpret_cast<const double2 *>(src + i);
+    else
+      dst[i] = src[i];
+  }
+}
+
+hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  long nb = ((long)n + ABFT_BLOCK * 4 - 1) / (ABFT_BLOCK * 4);
+  if (nb > 4096) nb = 4096;
+  if (aligned16(dst, src))
+    hipLaunchKernelGGL(copy_kernel<2>, dim3((unsigned)nb), dim3(ABFT_BLOCK), 0, s, dst, src, n);
+  else
+    hipLaunchKernelGGL(copy_kernel<1>, dim3((unsigned)nb), dim3(ABFT_BLOCK), 0, s, dst, src, n);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------ bandwidth probe --
 
 __global__ __launch_bounds__(ABFT_BLOCK) void stream_copy_kernel(double2 *__restrict__ dst,
