@@ -35,10 +35,15 @@ class Matrix:
 class Vector:
     def __init__(self, ctx, handle, n):
         self.ctx, self.h, self.N = ctx, handle, n
+        self._dptr = None
 
     @property
     def device_ptr(self):
-        return capi.load().abft_hip_vector_device_ptr(self.h)
+        # asked once: the address never changes, and every call of the C function
+        # first applies a deferred update (include/abft_hip.h)
+        if self._dptr is None:
+            self._dptr = capi.load().abft_hip_vector_device_ptr(self.h)
+        return self._dptr
 
 
 class HIPContext:

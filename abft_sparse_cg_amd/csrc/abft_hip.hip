@@ -64,6 +64,17 @@ struct abft_hip_ctx {
     uint32_t seq = 0;
     double value = 0.0;
   } fused;
+  // cross-call fusion no. 2: calc_xr leaves x += alpha p to the calc_p that follows
+  // it (see kernels.hip, calc_r_kernel); anything else that comes first flushes it
+  bool defer_enabled = true;
+  struct {
+    bool active = false, on_dev = false;
+    double *x = nullptr;
+    const double *p = nullptr;
+    int n = 0;
+    double alpha = 0.0;
+  } defer;
+  double *alpha_dev = nullptr;  // alpha of the deferred update when it was formed on the device
   unsigned prof = 0;  // bit k: bracket launches of kernel k with HIP events
   unsigned prof_stride = 1, prof_seen[ABFT_K_COUNT] = {};  // ... every prof_stride-th launch of it
   ProfSlot prof_k[ABFT_K_COUNT];
@@ -93,13 +104,27 @@ struct abft_hip_vector {
   int n = 0;
   bool owns = true;
   double *host = nullptr;  // pinned staging for map/unmap
+  abft_hip_vector *root = nullptr;  // the allocation a view looks into (itself for an owner)
+  bool exposed = false;             // root only: the raw device pointer was handed out
 };
 
 static constexpr uint32_t EVENT_CAP = 1u << 16;
 
-static int bind(abft_hip_ctx *ctx) {
+static int flush_deferred(abft_hip_ctx *ctx) {
+  if (!ctx->defer.active) return ABFT_OK;
+  ctx->defer.active = false;
+  HIPCHK(launch_axpy(ctx->defer.x, ctx->defer.p, ctx->defer.alpha, ctx->defer.on_dev ? ctx->alpha_dev : nullptr,
+                     ctx->defer.n, ctx->stream));
+  return ABFT_OK;
+}
+
+// Every entry point starts here.  Unless the caller is the calc_p that can absorb
+// it (keep_deferred), a pending x += alpha p is enqueued first, so no call ever
+// sees x or p in any state the unfused sequence would not have produced.
+static int bind(abft_hip_ctx *ctx, bool keep_deferred = false) {
   if (!ctx) return set_err(ABFT_ERR_INVALID, "null context");
   HIPCHK(hipSetDevice(ctx->device));
+  if (!keep_deferred) return flush_deferred(ctx);
   return ABFT_OK;
 }
 
@@ -188,6 +213,8 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   HIPCHK(hipMemset(ctx->ticket, 0, ABFT_TICKET_WORDS * sizeof(uint32_t)));
   if (const char *e = getenv("ABFT_HIP_SYNC")) ctx->spin_wait = strcmp(e, "stream") != 0;
   if (const char *e = getenv("ABFT_HIP_FUSE_DOT")) ctx->fuse_enabled = strcmp(e, "0") != 0;
+  if (const char *e = getenv("ABFT_HIP_FUSE_X")) ctx->defer_enabled = strcmp(e, "0") != 0;
+  HIPCHK(hipMalloc((void **)&ctx->alpha_dev, sizeof(double)));
   HIPCHK(hipHostMalloc((void **)&ctx->host_slot, sizeof(HostSlot), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->host_slot, 0, sizeof(HostSlot));
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->host_slot_dev, ctx->host_slot, 0));
@@ -218,10 +245,12 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
 extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   if (!ctx) return ABFT_OK;
   (void)hipSetDevice(ctx->device);
+  (void)flush_deferred(ctx);
   (void)hipStreamSynchronize(ctx->stream);
   for (int k = 0; k < ABFT_K_COUNT; k++) KernelTimer::fold(ctx, k);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(ctx->partials);
+  (void)hipFree(ctx->alpha_dev);
   (void)hipFree(ctx->ticket);
   (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
@@ -671,7 +700,7 @@ extern "C" int abft_hip_vector_create(abft_hip_ctx *ctx, int N, abft_hip_vector 
   if (!vec || N < 0) return set_err(ABFT_ERR_INVALID, "bad vector arguments");
   abft_hip_vector *v = new (std::nothrow) abft_hip_vector();
   if (!v) return set_err(ABFT_ERR_NOMEM, "vector allocation failed");
-  v->ctx = ctx; v->n = N; v->owns = true;
+  v->ctx = ctx; v->n = N; v->owns = true; v->root = v;
   if (hipMalloc((void **)&v->d, ((size_t)N + 2) * sizeof(double)) != hipSuccess) {
     delete v;
     return set_err(ABFT_ERR_NOMEM, "hipMalloc of %zu bytes failed", ((size_t)N + 2) * sizeof(double));
@@ -687,6 +716,7 @@ extern "C" int abft_hip_vector_view(abft_hip_vector *parent, int offset, int N, 
   abft_hip_vector *v = new (std::nothrow) abft_hip_vector();
   if (!v) return set_err(ABFT_ERR_NOMEM, "vector allocation failed");
   v->ctx = parent->ctx; v->d = parent->d + offset; v->n = N; v->owns = false;
+  v->root = parent->root ? parent->root : parent;
   *vec = v;
   return ABFT_OK;
 }
@@ -730,7 +760,14 @@ extern "C" int abft_hip_vector_copy(abft_hip_vector *dst, const abft_hip_vector 
   return ABFT_OK;
 }
 
-extern "C" void *abft_hip_vector_device_ptr(abft_hip_vector *vec) { return vec ? vec->d : nullptr; }
+// Hands out the raw pointer: from here on the caller may read the vector behind the
+// library's back, so a pending update is applied now and none is deferred on it again.
+extern "C" void *abft_hip_vector_device_ptr(abft_hip_vector *vec) {
+  if (!vec) return nullptr;
+  if (vec->ctx && vec->ctx->defer.active) (void)bind(vec->ctx);
+  (vec->root ? vec->root : vec)->exposed = true;
+  return vec->d;
+}
 extern "C" int abft_hip_vector_length(abft_hip_vector *vec) { return vec ? vec->n : -1; }
 
 // --------------------------------------------------------------- CG kernels --
@@ -813,6 +850,10 @@ extern "C" int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, con
   return ABFT_OK;
 }
 
+static bool disjoint(const abft_hip_vector *a, const abft_hip_vector *b) {
+  return a->d + a->n <= b->d || b->d + b->n <= a->d;
+}
+
 static int calc_xr_launch(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r, const abft_hip_vector *p,
                           const abft_hip_vector *w, double alpha, const ReduceOut &o,
                           const double *num = nullptr, const double *den = nullptr) {
@@ -820,8 +861,42 @@ static int calc_xr_launch(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector
   if (int rc = check_same(x, p, "calc_xr")) return rc;
   if (int rc = check_same(x, w, "calc_xr")) return rc;
   ctx->fused.valid = false;
+  // x += alpha p can wait for the calc_p that reads the same p next (one pass over p
+  // less per iteration) when nobody can look at x in between: x is not aliased by
+  // any other operand and its raw pointer has never been handed out
+  const bool defer = ctx->defer_enabled && x->n > 0 && !(x->root ? x->root : x)->exposed && disjoint(x, r) &&
+                     disjoint(x, p) && disjoint(x, w) && disjoint(r, p);
   KernelTimer t(ctx, ABFT_K_CALC_XR);
+  if (defer) {
+    HIPCHK(launch_calc_r(r->d, w->d, alpha, num, den, num ? ctx->alpha_dev : nullptr, x->n, o, ctx->stream));
+    ctx->defer.active = true;
+    ctx->defer.on_dev = num != nullptr;
+    ctx->defer.x = x->d; ctx->defer.p = p->d; ctx->defer.n = x->n; ctx->defer.alpha = alpha;
+    return ABFT_OK;
+  }
   HIPCHK(launch_calc_xr(x->d, r->d, p->d, w->d, alpha, num, den, x->n, o, ctx->stream));
+  return ABFT_OK;
+}
+
+// calc_p, or calc_p plus the x update the preceding calc_xr left behind
+static int calc_p_launch(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r, double beta,
+                         const double *num, const double *den) {
+  if (int rc = check_same(p, r, "calc_p")) return rc;
+  ctx->fused.valid = false;
+  if (ctx->defer.active) {
+    abft_hip_vector xv;  // just the range, for the overlap test
+    xv.d = ctx->defer.x; xv.n = ctx->defer.n;
+    if (ctx->defer.p == p->d && ctx->defer.n == p->n && disjoint(&xv, r)) {
+      ctx->defer.active = false;
+      KernelTimer t(ctx, ABFT_K_CALC_P);
+      HIPCHK(launch_calc_px(p->d, r->d, ctx->defer.x, beta, num, den, ctx->defer.alpha,
+                            ctx->defer.on_dev ? ctx->alpha_dev : nullptr, p->n, ctx->stream));
+      return ABFT_OK;
+    }
+    if (int rc = flush_deferred(ctx)) return rc;
+  }
+  KernelTimer t(ctx, ABFT_K_CALC_P);
+  HIPCHK(launch_calc_p(p->d, r->d, beta, num, den, p->n, ctx->stream));
   return ABFT_OK;
 }
 
@@ -843,12 +918,8 @@ extern "C" int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_
 }
 
 extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r, double beta) {
-  if (int rc = bind(ctx)) return rc;
-  if (int rc = check_same(p, r, "calc_p")) return rc;
-  ctx->fused.valid = false;
-  KernelTimer t(ctx, ABFT_K_CALC_P);
-  HIPCHK(launch_calc_p(p->d, r->d, beta, nullptr, nullptr, p->n, ctx->stream));
-  return ABFT_OK;
+  if (int rc = bind(ctx, true)) return rc;
+  return calc_p_launch(ctx, p, r, beta, nullptr, nullptr);
 }
 
 // ---- device-scalar forms: alpha and beta never leave the GPU -------------------
@@ -863,13 +934,12 @@ extern "C" int abft_hip_calc_xr_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *x,
 
 extern "C" int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r,
                                          const double *dev_num, const double *dev_den) {
-  if (int rc = bind(ctx)) return rc;
-  if (int rc = check_same(p, r, "calc_p")) return rc;
-  if (!dev_num || !dev_den) return set_err(ABFT_ERR_INVALID, "null device scalar");
-  ctx->fused.valid = false;
-  KernelTimer t(ctx, ABFT_K_CALC_P);
-  HIPCHK(launch_calc_p(p->d, r->d, 0.0, dev_num, dev_den, p->n, ctx->stream));
-  return ABFT_OK;
+  if (int rc = bind(ctx, true)) return rc;
+  if (!dev_num || !dev_den) {
+    (void)flush_deferred(ctx);
+    return set_err(ABFT_ERR_INVALID, "null device scalar");
+  }
+  return calc_p_launch(ctx, p, r, 0.0, dev_num, dev_den);
 }
 
 // Shared by abft_hip_spmv (dev_pair == nullptr: the fused product, if any, goes to

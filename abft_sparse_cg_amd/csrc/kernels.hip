@@ -1115,9 +1115,117 @@ hipError_t launch_calc_p(double *p, const double *r, double beta, const double *
   return hipGetLastError();
 }
 
-// copy_vector (reference CSR/CPUContext.cpp:76-80: memcpy of dst->N doubles).  A
-// kernel rather than hipMemcpyAsync: the runtime's device-to-device path took
-// ~1.3 ms per 80 MB vector in the driver's timed loop, this one the 27 us the bytes cost.
+// ---- calc_xr / calc_p with the x update moved (cross-call fusion, abft_hip.hip) ----
+// calc_xr reads p only for x += alpha p, and the calc_p that follows it in the CG loop
+// reads the same p again.  When the library sees that pair it runs calc_xr without its
+// x half (calc_r_kernel: 24 N bytes instead of 48 N) and lets calc_p do it
+// (calc_px_kernel: 40 N instead of 24 N) -- p is read once per iteration, 8 N bytes
+// less traffic, every x[i] and p[i] the same bits (same operands, same two roundings).
+
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(double *__restrict__ r, const double *__restrict__ w,
+                                                            double alpha, const double *num, const double *den,
+                                                            double *alpha_out, int n, ReduceOut out) {
+  __shared__ double s_w[4];
+  if (num) alpha = *num / *den;
+  if (alpha_out && blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;  // for the deferred x += alpha p
+  double acc = 0.0;
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n) {
+      double2 rv = *reinterpret_cast<double2 *>(r + i);
+      const double2 wv = *reinterpret_cast<const double2 *>(w + i);
+      rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
+      *reinterpret_cast<double2 *>(r + i) = rv;
+      acc += rv.x * rv.x;
+      acc += rv.y * rv.y;
+    } else {
+      const double rs = r[i] - alpha * w[i];
+      r[i] = rs;
+      acc += rs * rs;
+    }
+  }
+  acc = block_sum(acc, s_w);
+  reduce_finish(acc, out, s_w);
+}
+
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(double *__restrict__ p, const double *__restrict__ r,
+                                                             double *__restrict__ x, double beta,
+                                                             const double *num, const double *den, double alpha,
+                                                             const double *alpha_ptr, int n) {
+  if (num) beta = *num / *den;
+  if (alpha_ptr) alpha = *alpha_ptr;
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n) {
+      double2 pv = *reinterpret_cast<double2 *>(p + i);
+      double2 xv = *reinterpret_cast<double2 *>(x + i);
+      const double2 rv = *reinterpret_cast<const double2 *>(r + i);
+      xv.x += alpha * pv.x; xv.y += alpha * pv.y;  // calc_xr's x half, with p as calc_xr saw it
+      pv.x = rv.x + beta * pv.x;
+      pv.y = rv.y + beta * pv.y;
+      *reinterpret_cast<double2 *>(x + i) = xv;
+      *reinterpret_cast<double2 *>(p + i) = pv;
+    } else {
+      const double pv = p[i];
+      x[i] = x[i] + alpha * pv;
+      p[i] = r[i] + beta * pv;
+    }
+  }
+}
+
+// the deferred x += alpha p on its own, when something other than calc_p comes next
+template <int VEC>
+__global__ __launch_bounds__(ABFT_BLOCK) void axpy_kernel(double *__restrict__ x, const double *__restrict__ p,
+                                                          double alpha, const double *alpha_ptr, int n) {
+  if (alpha_ptr) alpha = *alpha_ptr;
+  const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
+  for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
+    if (VEC == 2 && i + 1 < n) {
+      double2 xv = *reinterpret_cast<double2 *>(x + i);
+      const double2 pv = *reinterpret_cast<const double2 *>(p + i);
+      xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+      *reinterpret_cast<double2 *>(x + i) = xv;
+    } else {
+      x[i] = x[i] + alpha * p[i];
+    }
+  }
+}
+
+hipError_t launch_calc_r(double *r, const double *w, double alpha, const double *num, const double *den,
+                         double *alpha_out, int n, const ReduceOut &out, hipStream_t s) {
+  const int nb = reduce_blocks(n);
+  if (aligned16(r, w))
+    hipLaunchKernelGGL(calc_r_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, r, w, alpha, num, den, alpha_out, n, out);
+  else
+    hipLaunchKernelGGL(calc_r_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, r, w, alpha, num, den, alpha_out, n, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_calc_px(double *p, const double *r, double *x, double beta, const double *num, const double *den,
+                          double alpha, const double *alpha_ptr, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int nb = reduce_blocks(n);
+  if (aligned16(p, r, x))
+    hipLaunchKernelGGL(calc_px_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, x, beta, num, den, alpha, alpha_ptr, n);
+  else
+    hipLaunchKernelGGL(calc_px_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, x, beta, num, den, alpha, alpha_ptr, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_axpy(double *x, const double *p, double alpha, const double *alpha_ptr, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int nb = reduce_blocks(n);
+  if (aligned16(x, p))
+    hipLaunchKernelGGL(axpy_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, p, alpha, alpha_ptr, n);
+  else
+    hipLaunchKernelGGL(axpy_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, p, alpha, alpha_ptr, n);
+  return hipGetLastError();
+}
+
+// copy_vector (reference CSR/CPUContext.cpp:76-80: memcpy of dst->N doubles), as an
+// ordinary kernel on the context's stream (capturable; no runtime copy path involved)
 template <int VEC>
 __global__ __launch_bounds__(ABFT_BLOCK) void copy_kernel(double *__restrict__ dst, const double *__restrict__ src,
                                                           int n) {

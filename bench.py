@@ -113,6 +113,9 @@ def single(args):
             if cnt:
                 us = ms * 1e3 / cnt
                 kernels[name] = {"avg_us": round(us, 2), "launches": cnt, "GBps": round(byts[name] / us / 1e3, 1)}
+                if name in ("calc_xr", "calc_p") and os.environ.get("ABFT_HIP_FUSE_X", "1") != "0":
+                    # GBps is on the reference's byte count; the x update actually runs inside calc_p
+                    kernels[name]["note"] = "x += alpha p deferred from calc_xr into calc_p (moves 24N / 40N bytes)"
                 if name == "dot" and os.environ.get("ABFT_HIP_FUSE_DOT", "1") != "0":
                     # dot(p,w) is formed inside the SpMV; what is timed here is the one-block fold of its partials
                     kernels[name] = {"avg_us": round(us, 2), "launches": cnt, "note": "fold of the SpMV's fused p.w partials"}

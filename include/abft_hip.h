@@ -144,6 +144,11 @@ int abft_hip_vector_map(abft_hip_vector *vec, double **host);
 int abft_hip_vector_unmap(abft_hip_vector *vec, double *host);
 /* reference CSR/CPUContext.cpp:77-80: copies dst->N doubles */
 int abft_hip_vector_copy(abft_hip_vector *dst, const abft_hip_vector *src);
+/* The raw device address (stable for the life of the vector), for callers that
+ * alias library memory, e.g. to hand it to a collective.  Work the caller
+ * enqueues on it must be ordered against the context's stream.  A vector whose
+ * address has been handed out is excluded from the deferred x update described
+ * at abft_hip_calc_xr; ask once and keep the value. */
 void *abft_hip_vector_device_ptr(abft_hip_vector *vec);
 int abft_hip_vector_length(abft_hip_vector *vec);
 
@@ -152,7 +157,11 @@ int abft_hip_vector_length(abft_hip_vector *vec);
 /* reference CSR/CPUContext.cpp:82-90 */
 int abft_hip_dot(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b,
                  double *result);
-/* reference CSR/CPUContext.cpp:92-105: x += alpha p; r -= alpha w; returns r.r */
+/* reference CSR/CPUContext.cpp:92-105: x += alpha p; r -= alpha w; returns r.r.
+ * The x half may be carried out by the abft_hip_calc_p that follows (it reads the
+ * same p: one pass over p less per iteration); any other call on the context
+ * applies it first, so callers observe exactly the reference's sequence.
+ * ABFT_HIP_FUSE_X=0 turns this off. */
 int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
                      const abft_hip_vector *p, const abft_hip_vector *w, double alpha,
                      double *result);

@@ -546,3 +546,76 @@ def test_spmv_in_two_parts_equals_one_launch(amd, mode, mat, lo, hi):
         assert bits_equal(y0, o.spmv(x))
     finally:
         ctx.close()
+
+
+def test_deferred_x_update_is_transparent(amd):
+    """calc_xr leaves x += alpha p to the calc_p that follows (cross-call fusion); any
+    other call applies it first.  x, r, p must be the reference's bits on every path."""
+    n = 5003
+    rng = np.random.default_rng(9)
+    x0, r0, p0, w0, q0 = (rng.standard_normal(n) for _ in range(5))
+    alpha, beta = 0.37, -1.25
+    ctx = amd.HIPContext("none", "csr")
+    try:
+        def fresh():
+            vs = [ctx.create_vector(n) for _ in range(5)]
+            for v, a in zip(vs, (x0, r0, p0, w0, q0)):
+                ctx.upload(v, a)
+            return vs
+        xr, rr_, pr = x0.copy(), r0.copy(), p0.copy()
+        want_rr = ora_calc_xr(xr, rr_, pr, w0, alpha)
+        p_after = pr.copy()
+        ora_calc_p(p_after, rr_, beta)
+
+        # (1) the CG order: calc_xr then calc_p -> one fused kernel does both halves
+        x, r, p, w, q = fresh()
+        got = ctx.calc_xr(x, r, p, w, alpha)
+        ctx.calc_p(p, r, beta)
+        assert abs(got - want_rr) <= 1e-13 * want_rr
+        assert bits_equal(ctx.download(x), xr) and bits_equal(ctx.download(r), rr_)
+        assert bits_equal(ctx.download(p), p_after)
+
+        # (2) x read right after calc_xr: the pending half is applied before the copy out
+        x, r, p, w, q = fresh()
+        ctx.calc_xr(x, r, p, w, alpha)
+        assert bits_equal(ctx.download(x), xr)
+        ctx.calc_p(p, r, beta)  # nothing pending any more: plain calc_p
+        assert bits_equal(ctx.download(p), p_after) and bits_equal(ctx.download(x), xr)
+
+        # (3) p overwritten before any calc_p: x must have used the old p
+        x, r, p, w, q = fresh()
+        ctx.calc_xr(x, r, p, w, alpha)
+        ctx.copy_vector(p, q)
+        assert bits_equal(ctx.download(x), xr) and bits_equal(ctx.download(p), q0)
+
+        # (4) a calc_p on ANOTHER vector comes next: not the pair, x still right
+        x, r, p, w, q = fresh()
+        ctx.calc_xr(x, r, p, w, alpha)
+        ctx.calc_p(q, r, beta)
+        qa = q0.copy()
+        ora_calc_p(qa, rr_, beta)
+        assert bits_equal(ctx.download(q), qa) and bits_equal(ctx.download(x), xr)
+        assert bits_equal(ctx.download(p), p0)
+
+        # (5) two calc_xr in a row, then calc_p
+        x, r, p, w, q = fresh()
+        ctx.calc_xr(x, r, p, w, alpha)
+        ctx.calc_xr(x, r, p, w, alpha)
+        ctx.calc_p(p, r, beta)
+        x2, r2 = xr.copy(), rr_.copy()
+        ora_calc_xr(x2, r2, pr, w0, alpha)
+        p2 = pr.copy()
+        ora_calc_p(p2, r2, beta)
+        assert bits_equal(ctx.download(x), x2) and bits_equal(ctx.download(p), p2)
+
+        # (6) a vector whose device address was handed out is never deferred
+        x, r, p, w, q = fresh()
+        assert x.device_ptr
+        ctx.calc_xr(x, r, p, w, alpha)
+        import torch
+        torch.cuda.synchronize()  # (not ctx.synchronize(): a library call would apply a pending update)
+        from abft_sparse_cg_amd.distributed import _DevMem
+        seen = torch.as_tensor(_DevMem(x.device_ptr, n), device="cuda:0").cpu().numpy()
+        assert bits_equal(seen, xr)
+    finally:
+        ctx.close()
