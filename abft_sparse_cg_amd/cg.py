@@ -209,6 +209,7 @@ def load_matrix(o, row0=0, row1=None):
 
 def run_single(o):
     from . import HIPContext, generators
+    from .context import fdiv
     cols, rows, vals, n, block = load_matrix(o)
     nnz = len(vals)
     ctx = HIPContext(o["mode"], o["fmt"])
@@ -231,9 +232,9 @@ def run_single(o):
     while itr < o["max_itrs"] and rr > o["conv"]:
         ctx.spmv(A, p, w)
         pw = ctx.dot(p, w)
-        alpha = rr / pw
+        alpha = fdiv(rr, pw)
         rr_new = ctx.calc_xr(x, r, p, w, alpha)
-        ctx.calc_p(p, r, rr_new / rr)
+        ctx.calc_p(p, r, fdiv(rr_new, rr))
         rr = rr_new
         if not o["quiet"]:
             print("iteration %5u :  rr = %12.4f" % (itr, rr))

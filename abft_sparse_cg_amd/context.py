@@ -270,6 +270,15 @@ def _libc_rand():
     return _libc.rand()
 
 
+def fdiv(a, b):
+    """a / b as the reference's C++ computes it (cg.cpp:102, 109): IEEE-754, so a zero
+    denominator gives inf / nan instead of Python's ZeroDivisionError"""
+    if b == 0.0:
+        a = float(a)
+        return float("nan") if a == 0.0 or a != a else float("inf") if (a > 0) == (str(float(b))[0] != "-") else float("-inf")
+    return a / b
+
+
 def cg_solve(ctx, A, b, x, r, p, w, max_itrs=1000, conv_threshold=1e-3, on_iteration=None):
     """The reference driver's CG loop, call for call (cg.cpp:87-118)."""
     ctx.copy_vector(r, b)
@@ -279,9 +288,9 @@ def cg_solve(ctx, A, b, x, r, p, w, max_itrs=1000, conv_threshold=1e-3, on_itera
     while itr < max_itrs and rr > conv_threshold:
         ctx.spmv(A, p, w)
         pw = ctx.dot(p, w)
-        alpha = rr / pw
+        alpha = fdiv(rr, pw)
         rr_new = ctx.calc_xr(x, r, p, w, alpha)
-        beta = rr_new / rr
+        beta = fdiv(rr_new, rr)
         ctx.calc_p(p, r, beta)
         rr = rr_new
         if on_iteration is not None:

@@ -31,6 +31,7 @@ import torch
 import torch.distributed as dist
 
 from . import capi
+from .context import fdiv
 
 
 class _DevMem:
@@ -331,12 +332,12 @@ class ShardedCG:
         self.exchange_finish(h)
         self.e.spmv(self.A, self.p_full, self.w, capi.PART_BOUNDARY)
         pw = self.dot(self.p, self.w)
-        alpha = self.rr / pw
+        alpha = fdiv(self.rr, pw)
         self.e.calc_xr_partial(self.x, self.r, self.p, self.w, alpha, self.scal)
         rr_new, nev = self._allreduce_scalar()
         if nev and self._collect_events():
             raise SystemExit(1)
-        beta = rr_new / self.rr
+        beta = fdiv(rr_new, self.rr)
         self.e.calc_p(self.p, self.r, beta)
         self.rr = rr_new
         return rr_new

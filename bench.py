@@ -68,6 +68,7 @@ def single(args):
 
     import abft_sparse_cg_amd as amd
     from abft_sparse_cg_amd import capi, generators
+    from abft_sparse_cg_amd.context import fdiv
 
     cols, rows, vals, n = generators.generate(args.spec)
     nnz = len(vals)
@@ -83,9 +84,9 @@ def single(args):
     def step():
         ctx.spmv(A, p, w)
         pw = ctx.dot(p, w)
-        alpha = state["rr"] / pw
+        alpha = fdiv(state["rr"], pw)
         rr_new = ctx.calc_xr(x, r, p, w, alpha)
-        ctx.calc_p(p, r, rr_new / state["rr"])
+        ctx.calc_p(p, r, fdiv(rr_new, state["rr"]))
         state["rr"] = rr_new
 
     for _ in range(args.warmup):
