@@ -999,7 +999,10 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   if (part == ABFT_PART_INTERIOR) return ABFT_OK;  // the boundary call folds and publishes
   if (do_fuse) {
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
-    HIPCHK(launch_fuse_finalize(fuse, nparts, ctx->stream));
+    ReduceOut big{};  // same outputs as the one-block fold, reached through the reduction protocol
+    big.partials = ctx->partials; big.ticket = ctx->ticket; big.dev_out = fuse.dev_out; big.host = fuse.host;
+    big.ev_count = fuse.ev_count; big.seq = fuse.seq;
+    HIPCHK(launch_fuse_finalize(fuse, nparts, big, ctx->stream));
   }
   if (to_host && do_fuse) {
     ctx->fused.valid = true;

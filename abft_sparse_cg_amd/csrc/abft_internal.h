@@ -151,7 +151,8 @@ hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P,
                                   EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
                                   hipStream_t s);
 // fuse == nullptr: plain SpMV; otherwise follow with launch_fuse_finalize
-hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s);
+// (`big`: where a multi-workgroup fold of many partials meets; see fold_partials_kernel)
+hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, const ReduceOut &big, hipStream_t s);
 hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);
 hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,

@@ -247,10 +247,6 @@ __global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t
   }
 }
 
-hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, hipStream_t s) {
-  hipLaunchKernelGGL(fuse_finalize_kernel, dim3(1), dim3(1024), 0, s, f, nblk);
-  return hipGetLastError();
-}
 
 // ----------------------------------------------------------------- CSR SpMV --
 
@@ -1000,6 +996,40 @@ __device__ __forceinline__ void reduce_finish(double block_value, const ReduceOu
       __hip_atomic_store(&o.host->seq, o.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+// Fold of many fused-dot partials (config 2: 48 806 of them, 390 KB) by several
+// workgroups: one workgroup reads at one CU's bandwidth and took 8-10 us.  Each
+// workgroup adds a contiguous chunk in a fixed order, then the chunks' sums meet
+// through the same last-arriver protocol as every other reduction.
+__global__ __launch_bounds__(ABFT_BLOCK) void fold_partials_kernel(const double *__restrict__ parts, uint32_t n,
+                                                                   uint32_t chunk, ReduceOut out) {
+  __shared__ double s_w[4];
+  const uint32_t lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
+  double acc = 0.0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 4u * ABFT_BLOCK) {
+    double v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t j = i + (uint32_t)k * ABFT_BLOCK;
+      v[k] = j < hi ? parts[j] : 0.0;
+    }
+    acc += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  acc = block_sum(acc, s_w);
+  reduce_finish(acc, out, s_w);
+}
+
+hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, const ReduceOut &big, hipStream_t s) {
+  if (nblk <= 8192u || !big.partials) {
+    hipLaunchKernelGGL(fuse_finalize_kernel, dim3(1), dim3(1024), 0, s, f, nblk);
+    return hipGetLastError();
+  }
+  uint32_t nb = (nblk + 2047u) / 2048u;
+  if (nb > 64u) nb = 64u;
+  const uint32_t chunk = (nblk + nb - 1u) / nb;
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(nb), dim3(ABFT_BLOCK), 0, s, f.partials, nblk, chunk, big);
+  return hipGetLastError();
 }
 
 // dot (reference CSR/CPUContext.cpp:82-90).  VEC=2: 16-byte loads.
