@@ -148,8 +148,9 @@ class ShardedCG:
         self.staged = staged
         # measurement aid: issue the collectives even at world size 1 (their host-side cost is the same)
         self.force_coll = os.environ.get("ABFT_FORCE_COLLECTIVES") == "1"
-        self._graph = None  # hipGraph of two iterations (run_fixed); False once capture has failed
+        self._graph = None  # hipGraphs of the iteration (run_fixed); False once capture has failed
         self._warm = False
+        self._replayed = False
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.G = dist.get_world_size(group) if dist.is_initialized() else 1
         assert len(bounds) == self.G + 1
@@ -445,6 +446,22 @@ class ShardedCG:
                 gi.replay()
             self.exchange_finish(h)
         rest[k & 1].replay()
+        if not self._replayed:
+            # first replay of a fresh capture: wait for it once, under a watchdog, so a
+            # collective that cannot run from a graph on this stack ends the job with a
+            # message within minutes instead of hanging it (ABFT_CG_GRAPH=0 avoids graphs)
+            import threading
+            def stuck():
+                sys.stderr.write("abft: the first hipGraph replay of the CG iteration did not finish in 180 s; "
+                                 "rerun with ABFT_CG_GRAPH=0\n")
+                sys.stderr.flush()
+                os._exit(70)
+            t = threading.Timer(180.0, stuck)
+            t.daemon = True
+            t.start()
+            self.e.tstream.synchronize()
+            t.cancel()
+            self._replayed = True
 
     def _allreduce_async(self, t):
         if self.G == 1 and not self.force_coll:
