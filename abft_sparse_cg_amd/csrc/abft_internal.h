@@ -72,6 +72,9 @@ struct CooDev {
 #ifndef ABFT_CFG_PANEL_EPT
 #define ABFT_CFG_PANEL_EPT 8  // elements per thread per tile of the panel-layout kernel (4: -9%)
 #endif
+#ifndef ABFT_CFG_SCHED_BARRIER
+#define ABFT_CFG_SCHED_BARRIER 1
+#endif
 #ifndef ABFT_CFG_NT
 #define ABFT_CFG_NT 1  // stream cols/vals with the non-temporal hint
 #endif
