@@ -37,13 +37,16 @@ def parse():
     ap.add_argument("--spec", default="laplace5:3162,3162", help="synthetic matrix (generators.cpp)")
     ap.add_argument("--mode", default="none")
     ap.add_argument("--fmt", default="csr", choices=["csr", "coo"])
-    ap.add_argument("--cpu-iters", type=int, default=40, help="CG iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-iters", type=int, default=160,
+                    help="CG iterations of the CPU baseline sample on all host cores, ~10 s (0 = skip); "
+                         "an eighth of that is also timed on one core")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--profile-all", action="store_true",
                     help="bracket all four kernels, not only the SpMV (costs ~10%% of the iteration rate)")
     ap.add_argument("--host-scalars", action="store_true",
                     help="N > 1: return both scalars to the host every iteration (default: device-resident)")
-    ap.add_argument("--probe", action="store_true", help="also measure the streaming-copy bandwidth of the device")
+    ap.add_argument("--no-probe", dest="probe", action="store_false",
+                    help="skip the streaming-copy bandwidth probe (the measured-peak denominator beside 8 TB/s)")
     return ap.parse_args()
 
 
@@ -142,10 +145,13 @@ def single(args):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import baseline  # the CPU checker, timed as a baseline only
         res = baseline.time_cg(cols, rows, vals, n, args.mode, args.cpu_iters)
+        one = baseline.time_cg(cols, rows, vals, n, args.mode, max(args.cpu_iters // 8, 2), threads=1)
         cpu = {"value": round(res["it_per_s"], 3), "unit": "CG iterations/s", "cores": res["cores"],
                "kind": res["kind"],
                "sample": "%d CG iterations of the same matrix (%s, -m %s), OpenMP spmv + serial vector ops as the "
-                         "reference, %.1f s" % (res["iters"], args.spec, args.mode, res["seconds"])}
+                         "reference, %.1f s" % (res["iters"], args.spec, args.mode, res["seconds"]),
+               "one_core": {"value": round(one["it_per_s"], 3), "cores": 1,
+                            "sample": "%d iterations, %.1f s" % (one["iters"], one["seconds"])}}
     return dt, n, nnz, roof, kernels, cpu, probe, rr_final
 
 

@@ -41,6 +41,10 @@ def time_cg(cols, rows, vals, n, mode, iters, threads=None):
     (conv threshold 0) from x=0, b = deterministic rhs."""
     threads = threads or host_cores()
     os.environ["OMP_NUM_THREADS"] = str(threads)
+    try:  # the OpenMP runtime reads the variable once; set the count directly for later calls
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    except OSError:
+        pass
     cols = np.ascontiguousarray(cols, dtype=np.uint32)
     rows = np.ascontiguousarray(rows, dtype=np.uint32)
     vals = np.ascontiguousarray(vals, dtype=np.float64)
