@@ -227,10 +227,14 @@ def sharded(args):
     if not args.no_profile:
         ms, cnt = eng.ctx.profile_read(capi.K_SPMV)
         if cnt:
-            us = ms * 1e3 / cnt
+            # a shard with interior rows multiplies in two launches (beside / after the exchange):
+            # the roofline figure is per SpMV, i.e. on the sum of the parts
+            parts = 2 if cg.interior else 1
+            us = ms * 1e3 / cnt * parts
             byts = spmv_bytes("csr", cg.n_loc, counts[rank])
             ach = byts / us / 1e3
-            kernels["spmv"] = {"avg_us": round(us, 2), "launches": cnt, "GBps": round(ach, 1), "rank": rank}
+            kernels["spmv"] = {"avg_us": round(us, 2), "launches": cnt, "launches_per_spmv": parts,
+                               "GBps": round(ach, 1), "rank": rank}
             roof = {"bound": "hbm", "kernel": "spmv_csr_kernel<%s> (rank 0 shard)" % args.mode,
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_us": round(us, 2),
