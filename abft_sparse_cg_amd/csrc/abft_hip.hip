@@ -347,6 +347,8 @@ static bool plan_panels(int mode, const uint32_t *in_idx, const uint32_t *out_id
   const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
   const uint64_t nseg = ngroups * npanels;
   if (nseg == 0 || nseg > ((uint64_t)1 << 27)) return false;
+  // the per-segment offset tables (2 bytes per output and segment) must stay small next to the matrix itself
+  if (!force && nseg * (ABFT_PANEL_ROWS + 1) * sizeof(uint16_t) > (uint64_t)nnz * 3u) return false;
   {
     std::vector<uint32_t> last((size_t)n_out, 0);
     for (int i = 0; i < nnz; i++) {
