@@ -71,6 +71,7 @@ SIGNATURES = {
     "abft_hip_spmv": (C.c_int, [vp, vp, vp, vp]),
     "abft_hip_dot_dev": (C.c_int, [vp, vp, vp, vp]),
     "abft_hip_calc_xr_dev": (C.c_int, [vp, vp, vp, vp, vp, C.c_double, vp]),
+    "abft_hip_read_pair": (C.c_int, [vp, vp, f64p, f64p]),
     "abft_hip_spmv_dot_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp]),
     "abft_hip_matrix_set_interior": (C.c_int, [vp, C.c_int, C.c_int]),
     "abft_hip_spmv_part": (C.c_int, [vp, vp, vp, vp, C.c_int]),

@@ -924,6 +924,19 @@ extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft
   return calc_p_launch(ctx, p, r, beta, nullptr, nullptr);
 }
 
+// {sum, events} that a collective left in device memory -> the host, through the pinned
+// slot the host polls (cheaper than a copy plus a stream synchronise)
+extern "C" int abft_hip_read_pair(abft_hip_ctx *ctx, const double *dev_pair, double *value, double *events) {
+  if (int rc = bind(ctx, true)) return rc;  // touches no vector: a deferred x update may stay pending
+  if (!dev_pair || !value) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (!ctx->fused.have_value) ctx->fused.valid = false;  // the slot is about to be reused
+  const uint32_t seq = ++ctx->seq;
+  HIPCHK(launch_publish_pair(dev_pair, ctx->host_slot_dev, seq, ctx->stream));
+  if (int rc = scalar_from_host_slot(ctx, seq, value)) return rc;
+  if (events) *events = (double)ctx->host_slot->evcount;
+  return ABFT_OK;
+}
+
 // ---- device-scalar forms: alpha and beta never leave the GPU -------------------
 
 extern "C" int abft_hip_calc_xr_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,

@@ -173,6 +173,7 @@ hipError_t launch_calc_r(double *r, const double *w, double alpha, const double 
 hipError_t launch_calc_px(double *p, const double *r, double *x, double beta, const double *num, const double *den,
                           double alpha, const double *alpha_ptr, int n, hipStream_t s);
 hipError_t launch_axpy(double *x, const double *p, double alpha, const double *alpha_ptr, int n, hipStream_t s);
+hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq, hipStream_t s);
 hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s);
 hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s);
 hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s);

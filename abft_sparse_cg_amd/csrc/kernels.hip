@@ -1260,6 +1260,23 @@ hipError_t launch_axpy(double *x, const double *p, double alpha, const double *a
   return hipGetLastError();
 }
 
+// {value, count} in device memory (e.g. what a collective left there) -> the pinned host
+// slot, published like a reduction's result so the host can poll for it
+__global__ void publish_pair_kernel(const double *pair, HostSlot *host, uint32_t seq) {
+  const double v = __hip_atomic_load(pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double c = __hip_atomic_load(pair + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&host->value, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host->evcount, c > 0.0 ? (c < 4.0e9 ? (uint32_t)c : 0xffffffffu) : 0u, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __hip_atomic_store(&host->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(publish_pair_kernel, dim3(1), dim3(1), 0, s, pair, host, seq);
+  return hipGetLastError();
+}
+
 // copy_vector (reference CSR/CPUContext.cpp:76-80: memcpy of dst->N doubles), as an
 // ordinary kernel on the context's stream (capturable; no runtime copy path involved)
 template <int VEC>

@@ -1,16 +1,35 @@
 // HIPContext.cpp -- see HIPContext.h.  Shared by cg-csr and cg-coo.
 #include "HIPContext.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+
+#include "comm.h"
 
 HIPContextBase::HIPContextBase(int format, int mode)
-  : ctx_(NULL), format_(format), mode_(mode)
+  : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
+    r0_(0), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL)
 {
-  int device = 0;
+  int device = comm_ ? comm_->local_rank() : 0;
   if (const char *env = getenv("ABFT_HIP_DEVICE"))
     device = atoi(env);
   check(abft_hip_init(device, &ctx_), "abft_hip_init");
+  if (comm_)
+  {
+    if (format_ != ABFT_FMT_CSR)
+    {
+      fprintf(stderr, "hip backend: the row-partitioned target shards CSR (cg-csr); cg-coo runs on one GPU\n");
+      exit(2);
+    }
+    comm_->enable_device_collectives(device);
+    check(abft_hip_vector_create(ctx_, 2, &pair_), "abft_hip_vector_create");
+    pair_dev_ = (double *)abft_hip_vector_device_ptr(pair_);
+    // every process runs the whole driver; the job's stdout is rank 0's
+    if (comm_->rank() != 0 && !freopen("/dev/null", "w", stdout))
+      exit(2);
+  }
 }
 
 HIPContextBase::~HIPContextBase()
@@ -18,7 +37,14 @@ HIPContextBase::~HIPContextBase()
   if (ctx_)
   {
     report_events(true);
+    if (pair_)
+      abft_hip_vector_destroy(pair_);
     abft_hip_shutdown(ctx_);
+  }
+  if (comm_)
+  {
+    comm_->barrier();
+    delete comm_;
   }
 }
 
@@ -33,17 +59,46 @@ void HIPContextBase::check(int rc, const char *what)
 
 // Print queued events the way the reference prints them while it runs, and
 // stop like it does on a fatal one.
+//
+// Row-partitioned: a collective -- every rank calls it at the same point of the
+// driver (forced at map_vector / destroy_matrix / the destructor, or after an
+// all-reduce that summed a non-zero event count).  The ranks' events (global
+// element indices) are merged in index order and cut after the first fatal one,
+// which is what a single-process run prints; all ranks then stop together.
+static bool event_before(const abft_event &a, const abft_event &b)
+{
+  return a.index != b.index ? a.index < b.index : a.kind < b.kind;
+}
+
 void HIPContextBase::report_events(bool force)
 {
-  if (!force && abft_hip_pending_events(ctx_) == 0)
+  if (!comm_ && !force && abft_hip_pending_events(ctx_) == 0)
     return;
   static abft_event events[4096];
   int count = 0, fatal = 0;
   check(abft_hip_drain_events(ctx_, events, 4096, &count, &fatal), "abft_hip_drain_events");
-  char line[160];
-  for (int i = 0; i < count; i++)
+  std::vector<abft_event> all(events, events + count);
+  if (comm_)
   {
-    abft_format_event(&events[i], line, sizeof(line));
+    std::vector<char> bytes;
+    std::vector<size_t> sizes;
+    comm_->allgatherv(events, (size_t)count * sizeof(abft_event), bytes, sizes);
+    all.resize(bytes.size() / sizeof(abft_event));
+    if (!all.empty())
+      memcpy(all.data(), bytes.data(), all.size() * sizeof(abft_event));
+    std::stable_sort(all.begin(), all.end(), event_before);
+    fatal = 0;
+    for (size_t i = 0; i < all.size() && !fatal; i++)
+      if (abft_event_is_fatal(all[i].kind))
+      {
+        fatal = 1;
+        all.resize(i + 1);
+      }
+  }
+  char line[160];
+  for (size_t i = 0; i < all.size(); i++)
+  {
+    abft_format_event(&all[i], line, sizeof(line));
     fputs(line, stdout);
   }
   if (fatal)
@@ -53,16 +108,84 @@ void HIPContextBase::report_events(bool force)
   }
 }
 
+// {partial sum, queued events} of this rank -> {sum over ranks, total events}:
+// on the GPU stream through RCCL when that is in use, else staged through the host.
+double HIPContextBase::reduce_scalar(abft_hip_vector *pair)
+{
+  double v[2] = {0.0, 0.0};
+  (void)pair;
+  double *dev = pair_dev_;
+  if (comm_->device_collectives())
+    comm_->allreduce_sum_device(dev, 2, abft_hip_get_stream(ctx_));
+  check(abft_hip_read_pair(ctx_, dev, &v[0], &v[1]), "abft_hip_read_pair");
+  if (!comm_->device_collectives())
+    comm_->allreduce_sum(v, 2);
+  if (v[1] > 0.0)
+    report_events(true);
+  return v[0];
+}
+
 cg_matrix* HIPContextBase::create_matrix(const uint32_t *columns, const uint32_t *rows,
                                          const double *values, int N, int nnz)
 {
   cg_matrix *M = new cg_matrix;
   M->N = N;
   M->nnz = nnz;
+  M->nnz_local = nnz;
+  M->nnz_before = 0;
   M->handle = NULL;
-  check(abft_hip_matrix_create_shard(ctx_, format_, mode_, columns, rows, values, N, N, nnz, 0,
-                                     &M->handle),
-        "abft_hip_matrix_create");
+  if (!comm_)
+  {
+    check(abft_hip_matrix_create_shard(ctx_, format_, mode_, columns, rows, values, N, N, nnz, 0,
+                                       &M->handle),
+          "abft_hip_matrix_create");
+    return M;
+  }
+
+  // ---- row blocks of (nearly) equal non-zero count; every rank computes the same cut ----
+  const int G = comm_->size(), me = comm_->rank();
+  if (N < G)
+  {
+    fprintf(stderr, "hip backend: %d ranks for a matrix of %d rows\n", G, N);
+    exit(2);
+  }
+  bounds_.assign(G + 1, 0);
+  bounds_[G] = N;
+  for (int g = 1; g < G; g++)
+  {
+    int row = nnz ? (int)rows[(size_t)((unsigned long long)nnz * g / G)] : (int)((long long)N * g / G);
+    row = std::max(row, bounds_[g - 1] + 1);   // at least one row each ...
+    row = std::min(row, N - (G - g));          // ... and room for the ranks behind
+    bounds_[g] = row;
+  }
+  slot_ = 0;
+  for (int g = 0; g < G; g++)
+    slot_ = std::max(slot_, bounds_[g + 1] - bounds_[g]);
+  n_pad_ = slot_ * G;
+  r0_ = bounds_[me];
+  n_loc_ = bounds_[me + 1] - r0_;
+  const uint32_t *lo = std::lower_bound(rows, rows + nnz, (uint32_t)r0_);
+  const uint32_t *hi = std::lower_bound(rows, rows + nnz, (uint32_t)(r0_ + n_loc_));
+  const size_t e0 = lo - rows, cnt = hi - lo;
+  M->nnz_before = (unsigned)e0;
+  M->nnz_local = (unsigned)cnt;
+  // local rows; columns re-based to the slot-padded gathered vector (slot g at [g*slot, ...))
+  std::vector<uint32_t> lrows(cnt ? cnt : 1), pcols(cnt ? cnt : 1);
+  for (size_t i = 0; i < cnt; i++)
+  {
+    lrows[i] = rows[e0 + i] - (uint32_t)r0_;
+    const uint32_t c = columns[e0 + i];
+    if (c >= (uint32_t)N)
+    {
+      pcols[i] = (uint32_t)n_pad_;  // out of range stays out of range (the kernel reads 0.0, as on one GPU)
+      continue;
+    }
+    const int owner = (int)(std::upper_bound(bounds_.begin(), bounds_.end(), (int)c) - bounds_.begin()) - 1;
+    pcols[i] = (uint32_t)(owner * slot_ + ((int)c - bounds_[owner]));
+  }
+  check(abft_hip_matrix_create_shard(ctx_, format_, mode_, pcols.data(), lrows.data(), values + e0, n_loc_,
+                                     n_pad_, (int)cnt, (uint32_t)e0, &M->handle),
+        "abft_hip_matrix_create_shard");
   return M;
 }
 
@@ -78,13 +201,33 @@ cg_vector* HIPContextBase::create_vector(int N)
   cg_vector *v = new cg_vector;
   v->N = N;
   v->handle = NULL;
-  check(abft_hip_vector_create(ctx_, N, &v->handle), "abft_hip_vector_create");
+  v->full = NULL;
+  v->full_dev = NULL;
+  v->host_full = NULL;
+  if (!comm_)
+  {
+    check(abft_hip_vector_create(ctx_, N, &v->handle), "abft_hip_vector_create");
+    return v;
+  }
+  if (bounds_.empty() || N != bounds_.back())
+  {
+    fprintf(stderr, "hip backend: row-partitioned vectors follow the matrix (create_matrix first, length %d)\n",
+            bounds_.empty() ? -1 : bounds_.back());
+    exit(2);
+  }
+  // any vector may become an spmv input: its slice lives inside a gathered buffer
+  check(abft_hip_vector_create(ctx_, n_pad_, &v->full), "abft_hip_vector_create");
+  check(abft_hip_vector_view(v->full, comm_->rank() * slot_, n_loc_, &v->handle), "abft_hip_vector_view");
   return v;
 }
 
 void HIPContextBase::destroy_vector(cg_vector *vec)
 {
+  fused_vec_ = fused_res_ = NULL;
   check(abft_hip_vector_destroy(vec->handle), "abft_hip_vector_destroy");
+  if (vec->full)
+    check(abft_hip_vector_destroy(vec->full), "abft_hip_vector_destroy");
+  free(vec->host_full);
   delete vec;
 }
 
@@ -92,22 +235,51 @@ double* HIPContextBase::map_vector(cg_vector *v)
 {
   double *host = NULL;
   check(abft_hip_vector_map(v->handle, &host), "abft_hip_vector_map");
+  if (comm_)
+  {
+    // the driver reads and writes whole vectors: collect the slices (rank order = row order)
+    if (!v->host_full && !(v->host_full = (double *)malloc(sizeof(double) * (size_t)std::max(v->N, 1))))
+      exit(2);
+    std::vector<char> bytes;
+    std::vector<size_t> sizes;
+    comm_->allgatherv(host, sizeof(double) * (size_t)n_loc_, bytes, sizes);
+    if (bytes.size() != sizeof(double) * (size_t)v->N)
+    {
+      fprintf(stderr, "hip backend: gathered %zu bytes for a vector of %d\n", bytes.size(), v->N);
+      exit(2);
+    }
+    memcpy(v->host_full, bytes.data(), bytes.size());
+    host = v->host_full;
+  }
   report_events(true);  // map synchronises: anything an earlier spmv queued is visible now
   return host;
 }
 
 void HIPContextBase::unmap_vector(cg_vector *v, double *h)
 {
-  check(abft_hip_vector_unmap(v->handle, h), "abft_hip_vector_unmap");
+  fused_vec_ = fused_res_ = NULL;
+  // row-partitioned: every rank's driver filled the whole vector alike; keep this rank's rows
+  check(abft_hip_vector_unmap(v->handle, comm_ ? h + r0_ : h), "abft_hip_vector_unmap");
 }
 
 void HIPContextBase::copy_vector(cg_vector *dst, const cg_vector *src)
 {
+  fused_vec_ = fused_res_ = NULL;
   check(abft_hip_vector_copy(dst->handle, src->handle), "abft_hip_vector_copy");
 }
 
 double HIPContextBase::dot(const cg_vector *a, const cg_vector *b)
 {
+  if (comm_)
+  {
+    // dot(p, w) right after spmv(A, p, w): the shard's p.w is already in pair_
+    const bool served = fused_vec_ && ((a == fused_vec_ && b == fused_res_) || (a == fused_res_ && b == fused_vec_));
+    fused_vec_ = fused_res_ = NULL;  // the all-reduce below overwrites the partial
+    if (!served)
+      check(abft_hip_dot_dev(ctx_, a->handle, b->handle, pair_dev_),
+            "abft_hip_dot_dev");
+    return reduce_scalar(pair_);
+  }
   double result = 0.0;
   check(abft_hip_dot(ctx_, a->handle, b->handle, &result), "abft_hip_dot");
   report_events(false);
@@ -117,6 +289,14 @@ double HIPContextBase::dot(const cg_vector *a, const cg_vector *b)
 double HIPContextBase::calc_xr(cg_vector *x, cg_vector *r, const cg_vector *p, const cg_vector *w,
                                double alpha)
 {
+  fused_vec_ = fused_res_ = NULL;
+  if (comm_)
+  {
+    check(abft_hip_calc_xr_dev(ctx_, x->handle, r->handle, p->handle, w->handle, alpha,
+                               pair_dev_),
+          "abft_hip_calc_xr_dev");
+    return reduce_scalar(pair_);
+  }
   double result = 0.0;
   check(abft_hip_calc_xr(ctx_, x->handle, r->handle, p->handle, w->handle, alpha, &result),
         "abft_hip_calc_xr");
@@ -126,12 +306,39 @@ double HIPContextBase::calc_xr(cg_vector *x, cg_vector *r, const cg_vector *p, c
 
 void HIPContextBase::calc_p(cg_vector *p, const cg_vector *r, double beta)
 {
+  fused_vec_ = fused_res_ = NULL;
   check(abft_hip_calc_p(ctx_, p->handle, r->handle, beta), "abft_hip_calc_p");
 }
 
 void HIPContextBase::spmv(const cg_matrix *mat, const cg_vector *vec, cg_vector *result)
 {
-  check(abft_hip_spmv(ctx_, mat->handle, vec->handle, result->handle), "abft_hip_spmv");
+  if (!comm_)
+  {
+    check(abft_hip_spmv(ctx_, mat->handle, vec->handle, result->handle), "abft_hip_spmv");
+    return;
+  }
+  // all-gather of the input vector: every rank's slice into its slot of the gathered buffer
+  if (comm_->device_collectives())
+  {
+    cg_vector *v = const_cast<cg_vector *>(vec);
+    if (!v->full_dev)
+      v->full_dev = (double *)abft_hip_vector_device_ptr(v->full);
+    comm_->allgather_device(v->full_dev, (size_t)slot_, abft_hip_get_stream(ctx_));
+  }
+  else
+  {
+    double *h = NULL;
+    check(abft_hip_vector_map(vec->full, &h), "abft_hip_vector_map");
+    std::vector<double> all((size_t)n_pad_);
+    comm_->allgather(h + (size_t)comm_->rank() * slot_, sizeof(double) * (size_t)slot_, all.data());
+    check(abft_hip_vector_unmap(vec->full, all.data()), "abft_hip_vector_unmap");
+  }
+  // the SpMV also leaves this shard's vec.result in pair_, for the dot that usually follows
+  check(abft_hip_spmv_dot_dev(ctx_, mat->handle, vec->full, result->handle, comm_->rank() * slot_,
+                              pair_dev_),
+        "abft_hip_spmv_dot_dev");
+  fused_vec_ = vec;
+  fused_res_ = result;
 }
 
 // The host half of inject_bitflip: the same 1 + num_flips rand() draws, bit
@@ -139,6 +346,29 @@ void HIPContextBase::spmv(const cg_matrix *mat, const cg_vector *vec, cg_vector 
 // COO/CPUContext.cpp:123-140); the XOR itself happens on the device.
 void HIPContextBase::inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_flips)
 {
+  if (comm_)
+  {
+    // rank 0 draws (and prints) like the reference; the owner of the element flips it
+    std::vector<int> msg(2 + std::max(num_flips, 0), 0);
+    if (comm_->rank() == 0)
+    {
+      msg[0] = rand() % mat->nnz;
+      int first = 0, width = 96;
+      if (kind == VALUE) width = 64;
+      else if (kind == INDEX) { first = 64; width = 32; }
+      for (int i = 0; i < num_flips; i++)
+      {
+        msg[2 + i] = (rand() % width) + first;
+        printf("*** flipping bit %d at index %d ***\n", msg[2 + i], msg[0]);
+      }
+    }
+    comm_->bcast(msg.data(), sizeof(int) * msg.size(), 0);
+    const unsigned index = (unsigned)msg[0];
+    if (index >= mat->nnz_before && index < mat->nnz_before + mat->nnz_local)
+      for (int i = 0; i < num_flips; i++)
+        check(abft_hip_inject(mat->handle, index - mat->nnz_before, &msg[2 + i], 1), "abft_hip_inject");
+    return;
+  }
   int index = rand() % mat->nnz;
 
   int first = 0, width;

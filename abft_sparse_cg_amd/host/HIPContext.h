@@ -15,21 +15,39 @@
 //
 // A failing library call (no GPU, out of memory, bad shapes) is fatal too:
 // message on stderr, exit(2).  There is no CPU fallback.
+//
+// Several GPUs: start one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK /
+// MASTER_ADDR / MASTER_PORT set (host/mgpu-run does; so does torch.distributed.run)
+// and every process runs the unchanged driver.  The backend then keeps a row block of
+// the matrix (cut by non-zeros) and the matching slices of every vector on its GPU:
+// spmv is preceded by an all-gather of the input vector, dot and calc_xr end in an
+// all-reduce of {partial sum, queued events}, map_vector hands the driver the whole
+// vector, events carry global element indices and are printed once, by rank 0, whose
+// stdout is the job's (the other ranks' is discarded).  CSR only.  See comm.h.
 #pragma once
+#include <vector>
+
 #include "CGContext.h"
 #include "abft_hip.h"
+
+class Comm;
 
 struct cg_matrix
 {
   abft_hip_matrix *handle;
   unsigned N;
-  unsigned nnz;
+  unsigned nnz;       // of the whole matrix
+  unsigned nnz_local; // sharded: elements of this rank's row block, the first being element nnz_before
+  unsigned nnz_before;
 };
 
 struct cg_vector
 {
-  abft_hip_vector *handle;
+  abft_hip_vector *handle;  // what the kernels work on: the whole vector, or this rank's slice
   int N;
+  abft_hip_vector *full;    // sharded: the slot-padded gathered buffer `handle` is a view into
+  double *full_dev;         // sharded: its device address, once an spmv has asked for it
+  double *host_full;        // sharded: map_vector's whole-vector staging
 };
 
 class HIPContextBase : public CGContext
@@ -59,10 +77,20 @@ public:
 private:
   void check(int rc, const char *what);
   void report_events(bool force);
+  double reduce_scalar(abft_hip_vector *pair);
 
   abft_hip_ctx *ctx_;
   int format_;
   int mode_;
+
+  // ---- row-partitioned mode (comm_ != NULL) ----
+  Comm *comm_;
+  std::vector<int> bounds_;      // row-block boundaries, size() + 1 entries
+  int slot_, n_pad_, n_loc_, r0_; // slot length, padded vector length, this rank's rows [r0_, r0_ + n_loc_)
+  abft_hip_vector *pair_;        // two doubles on the device: {partial sum, queued events}
+  double *pair_dev_;             // ... their address (asked once: see abft_hip_vector_device_ptr)
+  const cg_vector *fused_vec_;   // the last spmv also left vec.result in pair_ (until anything else runs)
+  const cg_vector *fused_res_;
 };
 
 template<int FORMAT, int MODE>

@@ -1,0 +1,264 @@
+// comm.cpp -- see comm.h.  Plain POSIX sockets; nothing here touches the GPU.
+#include "comm.h"
+
+#include <arpa/inet.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+static void die(const char *what)
+{
+  fflush(stdout);
+  fprintf(stderr, "hip backend (comm): %s: %s\n", what, strerror(errno));
+  exit(2);
+}
+
+static int env_int(const char *name, int fallback)
+{
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : fallback;
+}
+
+Comm* Comm::from_env()
+{
+  const int world = env_int("WORLD_SIZE", 1);
+  // (ABFT_COMM_FORCE=1: take the partitioned code path -- and RCCL -- with a single rank, for tests)
+  if (world <= 1 && env_int("ABFT_COMM_FORCE", 0) == 0)
+    return NULL;
+  Comm *c = new Comm();
+  c->size_ = world < 1 ? 1 : world;
+  c->rank_ = env_int("RANK", 0);
+  c->local_rank_ = env_int("LOCAL_RANK", c->rank_);
+  if (c->rank_ < 0 || c->rank_ >= world)
+  {
+    fprintf(stderr, "hip backend (comm): RANK %d outside [0,%d)\n", c->rank_, world);
+    exit(2);
+  }
+  const char *addr = getenv("MASTER_ADDR");
+  c->connect_star(addr && *addr ? addr : "127.0.0.1", env_int("MASTER_PORT", 29400));
+  return c;
+}
+
+Comm::~Comm()
+{
+  if (rccl_)
+    abft_rccl_destroy(rccl_);
+  for (size_t i = 0; i < peers_.size(); i++)
+    if (peers_[i] >= 0)
+      close(peers_[i]);
+  if (listen_fd_ >= 0)
+    close(listen_fd_);
+}
+
+void Comm::enable_device_collectives(int device)
+{
+  const char *mode = getenv("ABFT_COMM");
+  if (mode && !strcmp(mode, "tcp"))
+    return;
+  rccl_ = abft_rccl_init(this, device);  // NULL when built without RCCL
+}
+
+// Rank 0 listens and accepts size-1 connections; every other rank connects
+// (retrying while rank 0 is still starting) and introduces itself by its rank.
+void Comm::connect_star(const char *addr, int port)
+{
+  const int one = 1;
+  if (rank_ == 0)
+  {
+    listen_fd_ = socket(AF_INET, SOCK_STREAM, 0);
+    if (listen_fd_ < 0) die("socket");
+    setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+    sockaddr_in sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET;
+    sa.sin_port = htons((uint16_t)port);
+    sa.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (bind(listen_fd_, (sockaddr *)&sa, sizeof(sa)) < 0) die("bind (MASTER_PORT in use?)");
+    if (listen(listen_fd_, size_) < 0) die("listen");
+    peers_.assign(size_, -1);
+    for (int k = 1; k < size_; k++)
+    {
+      int fd = accept(listen_fd_, NULL, NULL);
+      if (fd < 0) die("accept");
+      setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      int who = -1;
+      recv_all(fd, &who, sizeof(who));
+      if (who <= 0 || who >= size_ || peers_[who] >= 0)
+      {
+        fprintf(stderr, "hip backend (comm): unexpected rank %d at rendezvous\n", who);
+        exit(2);
+      }
+      peers_[who] = fd;
+    }
+    return;
+  }
+  sockaddr_in sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sin_family = AF_INET;
+  sa.sin_port = htons((uint16_t)port);
+  if (inet_pton(AF_INET, addr, &sa.sin_addr) != 1)
+  {
+    fprintf(stderr, "hip backend (comm): MASTER_ADDR '%s' is not an IPv4 address\n", addr);
+    exit(2);
+  }
+  int fd = -1;
+  for (int attempt = 0; attempt < 600; attempt++)  // up to ~60 s for rank 0 to come up
+  {
+    fd = socket(AF_INET, SOCK_STREAM, 0);
+    if (fd < 0) die("socket");
+    if (connect(fd, (sockaddr *)&sa, sizeof(sa)) == 0)
+      break;
+    close(fd);
+    fd = -1;
+    usleep(100 * 1000);
+  }
+  if (fd < 0) die("connect to rank 0");
+  setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+  send_all(fd, &rank_, sizeof(rank_));
+  peers_.assign(1, fd);
+}
+
+void Comm::send_all(int fd, const void *buf, size_t n)
+{
+  const char *p = (const char *)buf;
+  while (n)
+  {
+    ssize_t k = send(fd, p, n, MSG_NOSIGNAL);
+    if (k < 0)
+    {
+      if (errno == EINTR) continue;
+      die("send (a peer ended early?)");
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+}
+
+void Comm::recv_all(int fd, void *buf, size_t n)
+{
+  char *p = (char *)buf;
+  while (n)
+  {
+    ssize_t k = recv(fd, p, n, 0);
+    if (k < 0)
+    {
+      if (errno == EINTR) continue;
+      die("recv");
+    }
+    if (k == 0)
+    {
+      // a peer that exits (e.g. with status 1 on a fatal ECC event it found first) closes its socket
+      fflush(stdout);
+      fprintf(stderr, "hip backend (comm): rank %d lost a peer\n", rank_);
+      exit(3);
+    }
+    p += k;
+    n -= (size_t)k;
+  }
+}
+
+void Comm::bcast(void *buf, size_t bytes, int root)
+{
+  if (rank_ == 0)
+  {
+    if (root != 0)
+      recv_all(peers_[root], buf, bytes);
+    for (int k = 1; k < size_; k++)
+      if (k != root)
+        send_all(peers_[k], buf, bytes);
+  }
+  else if (rank_ == root)
+    send_all(peers_[0], buf, bytes);
+  else
+    recv_all(peers_[0], buf, bytes);
+}
+
+void Comm::allgather(const void *mine, size_t bytes, void *all)
+{
+  char *out = (char *)all;
+  if (rank_ == 0)
+  {
+    memcpy(out, mine, bytes);
+    for (int k = 1; k < size_; k++)
+      recv_all(peers_[k], out + (size_t)k * bytes, bytes);
+    for (int k = 1; k < size_; k++)
+      send_all(peers_[k], out, (size_t)size_ * bytes);
+  }
+  else
+  {
+    send_all(peers_[0], mine, bytes);
+    recv_all(peers_[0], out, (size_t)size_ * bytes);
+  }
+}
+
+void Comm::allgatherv(const void *mine, size_t bytes, std::vector<char> &all, std::vector<size_t> &sizes)
+{
+  std::vector<unsigned long long> n(size_);
+  unsigned long long me = bytes;
+  allgather(&me, sizeof(me), n.data());
+  sizes.assign(n.begin(), n.end());
+  size_t total = 0;
+  for (int k = 0; k < size_; k++) total += sizes[k];
+  all.resize(total ? total : 1);
+  if (rank_ == 0)
+  {
+    size_t off = 0;
+    for (int k = 0; k < size_; k++)
+    {
+      if (k == 0) { if (bytes) memcpy(all.data(), mine, bytes); }
+      else if (sizes[k]) recv_all(peers_[k], all.data() + off, sizes[k]);
+      off += sizes[k];
+    }
+    if (total)
+      for (int k = 1; k < size_; k++)
+        send_all(peers_[k], all.data(), total);
+  }
+  else
+  {
+    if (bytes) send_all(peers_[0], mine, bytes);
+    if (total) recv_all(peers_[0], all.data(), total);
+  }
+  all.resize(total);
+}
+
+void Comm::allreduce_sum(double *v, int n)
+{
+  if (rank_ == 0)
+  {
+    std::vector<double> in(n);
+    for (int k = 1; k < size_; k++)  // fixed order: rank 1, 2, ... onto rank 0's values
+    {
+      recv_all(peers_[k], in.data(), sizeof(double) * n);
+      for (int i = 0; i < n; i++) v[i] += in[i];
+    }
+    for (int k = 1; k < size_; k++)
+      send_all(peers_[k], v, sizeof(double) * n);
+  }
+  else
+  {
+    send_all(peers_[0], v, sizeof(double) * n);
+    recv_all(peers_[0], v, sizeof(double) * n);
+  }
+}
+
+void Comm::barrier()
+{
+  double z = 0.0;
+  allreduce_sum(&z, 1);
+}
+
+void Comm::allreduce_sum_device(double *dev, int n, void *stream)
+{
+  abft_rccl_allreduce_sum(rccl_, dev, n, stream);
+}
+
+void Comm::allgather_device(double *full, size_t slot, void *stream)
+{
+  abft_rccl_allgather(rccl_, full, slot, rank_, stream);
+}

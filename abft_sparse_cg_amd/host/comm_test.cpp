@@ -1,0 +1,64 @@
+// comm_test -- exercises comm.h's host collectives between WORLD_SIZE processes
+// (tests/test_host_logic.py starts them); prints "ok" on every rank.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "comm.h"
+
+#define REQUIRE(c) do { if (!(c)) { fprintf(stderr, "rank %d: %s failed (line %d)\n", r, #c, __LINE__); return 1; } } while (0)
+
+int main()
+{
+  Comm *c = Comm::from_env();
+  if (!c) { printf("single\n"); return 0; }
+  const int r = c->rank(), n = c->size();
+  // bcast from every root
+  for (int root = 0; root < n; root++)
+  {
+    int v[3] = {r == root ? 100 + root : -1, r == root ? 7 : -1, r == root ? root * root : -1};
+    c->bcast(v, sizeof(v), root);
+    REQUIRE(v[0] == 100 + root && v[1] == 7 && v[2] == root * root);
+  }
+  // allreduce: rank-ordered sum, identical bits everywhere
+  double s[2] = {1.0 / (r + 1), (double)r};
+  c->allreduce_sum(s, 2);
+  double want = 0.0;
+  for (int k = 0; k < n; k++) want += 1.0 / (k + 1);
+  REQUIRE(s[0] == want && s[1] == n * (n - 1) / 2.0);
+  // allgather (equal sizes)
+  std::vector<int> all(n);
+  int mine = r * 3 + 1;
+  c->allgather(&mine, sizeof(mine), all.data());
+  for (int k = 0; k < n; k++) REQUIRE(all[k] == k * 3 + 1);
+  // allgatherv: rank k contributes k doubles (rank 0 nothing)
+  std::vector<double> part(r);
+  for (int i = 0; i < r; i++) part[i] = r + 0.25 * i;
+  std::vector<char> bytes;
+  std::vector<size_t> sizes;
+  c->allgatherv(part.data(), part.size() * sizeof(double), bytes, sizes);
+  REQUIRE((int)sizes.size() == n);
+  size_t off = 0;
+  for (int k = 0; k < n; k++)
+  {
+    REQUIRE(sizes[k] == k * sizeof(double));
+    for (int i = 0; i < k; i++)
+    {
+      double d;
+      memcpy(&d, bytes.data() + off + i * sizeof(double), sizeof(d));
+      REQUIRE(d == k + 0.25 * i);
+    }
+    off += sizes[k];
+  }
+  REQUIRE(bytes.size() == off);
+  // a large message (crosses socket buffer sizes)
+  std::vector<double> big(1 << 20, (double)r);
+  std::vector<double> got((size_t)n << 20);
+  c->allgather(big.data(), big.size() * sizeof(double), got.data());
+  for (int k = 0; k < n; k++) REQUIRE(got[((size_t)k << 20) + 12345] == (double)k);
+  REQUIRE(!c->device_collectives());
+  c->barrier();
+  delete c;
+  printf("ok\n");
+  return 0;
+}

@@ -189,6 +189,9 @@ int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip
 int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
                          const abft_hip_vector *p, const abft_hip_vector *w, double alpha,
                          double *dev_result);
+/* ... and back: the two doubles at `dev_pair` (after the collective summed them on
+ * the context's stream) delivered to the host through the pinned slot it polls. */
+int abft_hip_read_pair(abft_hip_ctx *ctx, const double *dev_pair, double *value, double *events);
 
 /* Device-scalar forms, for loops that keep alpha and beta on the device (no host
  * round trip per iteration; the row-partitioned solver's fixed-iteration loop):

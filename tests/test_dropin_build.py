@@ -1,5 +1,5 @@
 """The drop-in claim of INTEGRATION.md, checked where the reference tree exists:
-the five host-side files compile (as C++11) against the REFERENCE's own
+the host-side files compile (as C++11) against the REFERENCE's own
 CGContext.h and link into the reference's cg-csr / cg-coo next to its CPU
 backends, without touching cg.cpp or CGContext.*; --list then shows both targets.
 Build products go to a temporary directory; nothing of the reference is copied
@@ -24,16 +24,20 @@ def test_hipcontext_links_into_reference_driver(tmp_path, fmt):
     d = str(tmp_path)
     os.makedirs(os.path.join(d, fmt))
     shutil.copy(os.path.join(ROOT, "include", "abft_hip.h"), d)
-    for f in ("HIPContext.h", "HIPContext.cpp"):
+    for f in ("HIPContext.h", "HIPContext.cpp", "comm.h", "comm.cpp", "comm_rccl.cpp"):
         shutil.copy(os.path.join(PKG, "host", f), d)
     shutil.copy(os.path.join(PKG, "host", fmt, "HIPContext.cpp"), os.path.join(d, fmt))
     cxx = ["g++", "-std=gnu++11", "-I", d, "-I", REF, "-O1", "-Wall", "-Werror", "-fopenmp"]
     subprocess.check_call(cxx + ["-c", os.path.join(d, "HIPContext.cpp"), "-o", os.path.join(d, "HIPContext.o")])
+    # the multi-GPU plumbing: plain sockets; comm_rccl.cpp without -DABFT_WITH_RCCL is a stub (no ROCm headers)
+    for f in ("comm", "comm_rccl"):
+        subprocess.check_call(cxx + ["-c", os.path.join(d, f + ".cpp"), "-o", os.path.join(d, f + ".o")])
     subprocess.check_call(cxx + ["-c", os.path.join(d, fmt, "HIPContext.cpp"), "-o", os.path.join(d, fmt, "reg.o")])
     exe = os.path.join(d, "cg")
     subprocess.check_call(["g++", "-std=gnu++11", "-I", REF, "-O1", "-fno-strict-aliasing", "-fopenmp", "-w",
                            os.path.join(REF, "cg.cpp"), os.path.join(REF, "CGContext.cpp"),
                            os.path.join(REF, fmt, "CPUContext.cpp"), os.path.join(d, "HIPContext.o"),
+                           os.path.join(d, "comm.o"), os.path.join(d, "comm_rccl.o"),
                            os.path.join(d, fmt, "reg.o"), "-x", "c", os.path.join(REF, "mmio.c"), "-x", "none",
                            "-L" + PKG, "-labft_hip", "-Wl,-rpath," + PKG, "-o", exe])
     out = subprocess.run([exe, "--list"], capture_output=True, text=True).stdout

@@ -139,3 +139,65 @@ def test_python_driver_transcripts_match_reference(sharded):
     assert out.returncode == 1, out.stdout[-500:] + out.stderr[-1500:]
     assert out.stdout.rstrip("\n").endswith("[ECC] error detected at index 77")
     assert "*** flipping bit 3 at index 77 ***" in out.stdout
+
+
+# ---- several processes, one per GPU (host/mgpu-run + comm.cpp): the unchanged driver,
+# ---- row-partitioned by the backend.  On a one-GPU box the ranks share GPU 0 and the
+# ---- collectives are staged through the host (--one-gpu); RCCL runs at world size 1.
+
+def run_ranks(world, args, opts=()):
+    cmd = [os.path.join(HOST, "mgpu-run"), str(world)] + list(opts) + ["--", exe("csr")] + args
+    # world 1: still the partitioned code path, with the device collectives on RCCL
+    env = dict(os.environ, ABFT_COMM_FORCE="1") if world == 1 else None
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+
+
+def split_transcript(text):
+    # (RCCL announces itself on stdout when it initialises: version, HIP, ROCm, hostname, library path)
+    text = re.sub(r"(RCCL version|HIP version|ROCm version|Hostname|Librccl path) +:.*\n", "", text)
+    if text.startswith("\n\nimplementation") or text.startswith("\nimplementation"):
+        text = text.lstrip("\n")
+    rr = [float(m) for m in re.findall(r"iteration +\d+ :  rr = +([0-9.]+)", text)]
+    rest = re.sub(r"iteration +\d+ :  rr = +[0-9.]+\n", "", re.sub(r"time taken = .*", "", text))
+    return rr, rest
+
+
+@pytest.mark.parametrize("world,opts", [(1, ()), (2, ("--one-gpu",)), (3, ("--one-gpu",))])
+@pytest.mark.parametrize("mode,flip", [("none", None), ("secded", "1234:70"), ("sec7", "20000:13")])
+def test_cpp_driver_row_partitioned(world, opts, mode, flip):
+    """same report, same iteration count, rr lines within the reductions' tolerance, the ECC line
+    once and with its global index -- against the one-process run of the same executable"""
+    args = ["-f", MTX, "-t", "hip", "-m", mode] + (["--flip-at", flip] if flip else [])
+    one = run("csr", args)
+    many = run_ranks(world, args, opts)
+    assert one.returncode == 0 and many.returncode == 0, many.stdout[-400:] + many.stderr[-800:]
+    rr1, rest1 = split_transcript(one.stdout)
+    rrn, restn = split_transcript(many.stdout)
+    assert len(rr1) == len(rrn) > 50
+    assert all(abs(a - b) <= 1.01e-4 + 1e-10 * a for a, b in zip(rr1, rrn))
+    # everything else the driver prints (header, flip line, [ECC] line, iteration count, errors)
+    norm = lambda t: re.sub(r"(total error|max error) += +[0-9.]+", lambda m: m.group(0)[:-2], t).lstrip("\n")  # noqa: E731
+    assert norm(rest1) == norm(restn)
+    if flip:
+        assert many.stdout.count("[ECC] corrected bit %s at index %s\n" % tuple(reversed(flip.split(":")))) == 1
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_cpp_driver_row_partitioned_fatal_event_stops_every_rank(world):
+    many = run_ranks(world, ["-f", MTX, "-t", "hip", "-m", "sed", "--flip-at", "30000:70"],
+                     ("--one-gpu",) if world > 1 else ())
+    assert many.returncode == 1
+    assert many.stdout.count("[ECC] error detected at index 30000\n") == 1
+    assert "ran for" not in many.stdout
+
+
+def test_cpp_driver_row_partitioned_synthetic_fixed_iterations():
+    """the scattered matrix (all-gather of a vector every rank reads everywhere), -c 0"""
+    args = ["-t", "hip", "-m", "secded", "-s", "random:16384,12,3", "-c", "0", "-i", "40"]
+    one, many = run("csr", args), run_ranks(3, args, ("--one-gpu",))
+    assert one.returncode == 0 and many.returncode == 0, many.stderr[-800:]
+    rr1, rest1 = split_transcript(one.stdout)
+    rrn, restn = split_transcript(many.stdout)
+    assert len(rr1) == len(rrn) == 40
+    assert all(abs(a - b) <= 1.01e-4 + 1e-9 * a for a, b in zip(rr1, rrn))
+    assert "ran for 40 iterations" in many.stdout

@@ -99,3 +99,17 @@ def test_flip_draw_ranges_follow_the_reference():
     assert bit_range("csr", "INDEX") == (64, 96)
     assert bit_range("coo", "ANY") == (0, 128) and bit_range("coo", "VALUE") == (64, 128)
     assert bit_range("coo", "INDEX") == (0, 64)
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_host_collectives_of_the_cpp_multi_gpu_backend(world):
+    """host/comm.cpp (TCP star through rank 0: rendezvous, bcast, all-gather(v), rank-ordered
+    all-reduce) between `world` processes started by host/mgpu-run -- no GPU involved."""
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "abft_sparse_cg_amd", "host")
+    exe = os.path.join(host, "comm_test")
+    if not os.path.exists(exe):
+        pytest.skip("host/comm_test not built")
+    out = subprocess.run([os.path.join(host, "mgpu-run"), str(world), "--", exe], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout == "ok\n"  # rank 0's stdout is the job's; the other ranks' is discarded
