@@ -10,7 +10,7 @@
 
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
-    r0_(0), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL)
+    r0_(0), use_windows_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL)
 {
   int device = comm_ ? comm_->local_rank() : 0;
   if (const char *env = getenv("ABFT_HIP_DEVICE"))
@@ -170,7 +170,11 @@ cg_matrix* HIPContextBase::create_matrix(const uint32_t *columns, const uint32_t
   M->nnz_before = (unsigned)e0;
   M->nnz_local = (unsigned)cnt;
   // local rows; columns re-based to the slot-padded gathered vector (slot g at [g*slot, ...))
+  // ... noting which window of each peer's slot this rank reads, and which rows read a peer at all
   std::vector<uint32_t> lrows(cnt ? cnt : 1), pcols(cnt ? cnt : 1);
+  std::vector<int> need(2 * (size_t)G, 0);  // per peer: [lo, hi) inside its slot
+  std::vector<char> remote((size_t)n_loc_, 0);
+  for (int g = 0; g < G; g++) need[2 * g] = slot_;
   for (size_t i = 0; i < cnt; i++)
   {
     lrows[i] = rows[e0 + i] - (uint32_t)r0_;
@@ -181,11 +185,42 @@ cg_matrix* HIPContextBase::create_matrix(const uint32_t *columns, const uint32_t
       continue;
     }
     const int owner = (int)(std::upper_bound(bounds_.begin(), bounds_.end(), (int)c) - bounds_.begin()) - 1;
-    pcols[i] = (uint32_t)(owner * slot_ + ((int)c - bounds_[owner]));
+    const int off = (int)c - bounds_[owner];
+    pcols[i] = (uint32_t)(owner * slot_ + off);
+    if (owner != me)
+    {
+      need[2 * owner] = std::min(need[2 * owner], off);
+      need[2 * owner + 1] = std::max(need[2 * owner + 1], off + 1);
+      remote[lrows[i]] = 1;
+    }
   }
+  for (int g = 0; g < G; g++)
+    if (need[2 * g + 1] <= need[2 * g]) need[2 * g] = need[2 * g + 1] = 0;
+  all_need_.assign(2 * (size_t)G * G, 0);
+  comm_->allgather(need.data(), sizeof(int) * need.size(), all_need_.data());
+  long long moved = 0;
+  for (size_t k = 0; k < all_need_.size(); k += 2) moved += all_need_[k + 1] - all_need_[k];
+  // windows pay when they move well under half of what the all-gather moves (banded matrices: the halo)
+  use_windows_ = moved * 2 < (long long)N * (G - 1);
   check(abft_hip_matrix_create_shard(ctx_, format_, mode_, pcols.data(), lrows.data(), values + e0, n_loc_,
                                      n_pad_, (int)cnt, (uint32_t)e0, &M->handle),
         "abft_hip_matrix_create_shard");
+  // the longest run of rows that read only this rank's own slot can be multiplied while
+  // the exchange is in flight (row sums are never split: results stay bit-identical)
+  int best_lo = 0, best_hi = 0, run = 0;
+  for (int r = 0; r <= n_loc_; r++)
+  {
+    if (r < n_loc_ && !remote[r]) { run++; continue; }
+    if (run > best_hi - best_lo) { best_lo = r - run; best_hi = r; }
+    run = 0;
+  }
+  const bool interior = best_hi - best_lo >= std::max(n_loc_ / 4, 1);
+  if (interior)
+    check(abft_hip_matrix_set_interior(M->handle, best_lo, best_hi), "abft_hip_matrix_set_interior");
+  if (getenv("ABFT_HIP_VERBOSE"))
+    fprintf(stderr, "hip backend: rank %d of %d: rows [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
+            "interior rows [%d,%d)\n", me, G, r0_, r0_ + n_loc_, cnt, e0, use_windows_ ? "windows" : "all-gather",
+            comm_->device_collectives() ? "RCCL" : "TCP", interior ? best_lo : 0, interior ? best_hi : 0);
   return M;
 }
 
@@ -310,6 +345,69 @@ void HIPContextBase::calc_p(cg_vector *p, const cg_vector *r, double beta)
   check(abft_hip_calc_p(ctx_, p->handle, r->handle, beta), "abft_hip_calc_p");
 }
 
+// The exchange in front of a row-partitioned spmv: every rank's slice of `v` reaches the
+// ranks that read it -- an all-gather into the slots of the gathered buffer, or just the
+// windows each rank reads (the halo of a banded matrix).  With RCCL it runs on a side
+// stream between begin and finish, beside whatever is enqueued in between; staged through
+// the host (ABFT_COMM=tcp) it is synchronous and happens in finish, i.e. strictly after.
+void HIPContextBase::exchange_begin(cg_vector *v)
+{
+  if (!comm_->device_collectives())
+    return;
+  const int G = comm_->size(), me = comm_->rank();
+  if (!v->full_dev)
+    v->full_dev = (double *)abft_hip_vector_device_ptr(v->full);
+  comm_->device_exchange_begin(abft_hip_get_stream(ctx_));
+  if (!use_windows_)
+  {
+    comm_->allgather_device(v->full_dev, (size_t)slot_);
+    return;
+  }
+  std::vector<Comm::Piece> out, in;
+  for (int g = 0; g < G; g++)
+  {
+    if (g == me) continue;
+    const int *theirs = &all_need_[2 * ((size_t)g * G + me)];  // what rank g reads of my slot
+    if (theirs[1] > theirs[0])
+      out.push_back(Comm::Piece{g, v->full_dev + (size_t)me * slot_ + theirs[0], sizeof(double) * (size_t)(theirs[1] - theirs[0])});
+    const int *mine = &all_need_[2 * ((size_t)me * G + g)];    // what I read of rank g's slot
+    if (mine[1] > mine[0])
+      in.push_back(Comm::Piece{g, v->full_dev + (size_t)g * slot_ + mine[0], sizeof(double) * (size_t)(mine[1] - mine[0])});
+  }
+  comm_->sendrecv_device(out, in);
+}
+
+void HIPContextBase::exchange_finish(cg_vector *v)
+{
+  if (comm_->device_collectives())
+  {
+    comm_->device_exchange_finish(abft_hip_get_stream(ctx_));
+    return;
+  }
+  const int G = comm_->size(), me = comm_->rank();
+  double *h = NULL;
+  check(abft_hip_vector_map(v->full, &h), "abft_hip_vector_map");
+  std::vector<double> all(h, h + n_pad_);
+  if (!use_windows_)
+    comm_->allgather(h + (size_t)me * slot_, sizeof(double) * (size_t)slot_, all.data());
+  else
+  {
+    std::vector<Comm::Piece> out, in;
+    for (int g = 0; g < G; g++)
+    {
+      if (g == me) continue;
+      const int *theirs = &all_need_[2 * ((size_t)g * G + me)];
+      if (theirs[1] > theirs[0])
+        out.push_back(Comm::Piece{g, h + (size_t)me * slot_ + theirs[0], sizeof(double) * (size_t)(theirs[1] - theirs[0])});
+      const int *mine = &all_need_[2 * ((size_t)me * G + g)];
+      if (mine[1] > mine[0])
+        in.push_back(Comm::Piece{g, all.data() + (size_t)g * slot_ + mine[0], sizeof(double) * (size_t)(mine[1] - mine[0])});
+    }
+    comm_->exchange(out, in);
+  }
+  check(abft_hip_vector_unmap(v->full, all.data()), "abft_hip_vector_unmap");
+}
+
 void HIPContextBase::spmv(const cg_matrix *mat, const cg_vector *vec, cg_vector *result)
 {
   if (!comm_)
@@ -317,26 +415,17 @@ void HIPContextBase::spmv(const cg_matrix *mat, const cg_vector *vec, cg_vector 
     check(abft_hip_spmv(ctx_, mat->handle, vec->handle, result->handle), "abft_hip_spmv");
     return;
   }
-  // all-gather of the input vector: every rank's slice into its slot of the gathered buffer
-  if (comm_->device_collectives())
-  {
-    cg_vector *v = const_cast<cg_vector *>(vec);
-    if (!v->full_dev)
-      v->full_dev = (double *)abft_hip_vector_device_ptr(v->full);
-    comm_->allgather_device(v->full_dev, (size_t)slot_, abft_hip_get_stream(ctx_));
-  }
-  else
-  {
-    double *h = NULL;
-    check(abft_hip_vector_map(vec->full, &h), "abft_hip_vector_map");
-    std::vector<double> all((size_t)n_pad_);
-    comm_->allgather(h + (size_t)comm_->rank() * slot_, sizeof(double) * (size_t)slot_, all.data());
-    check(abft_hip_vector_unmap(vec->full, all.data()), "abft_hip_vector_unmap");
-  }
-  // the SpMV also leaves this shard's vec.result in pair_, for the dot that usually follows
-  check(abft_hip_spmv_dot_dev(ctx_, mat->handle, vec->full, result->handle, comm_->rank() * slot_,
-                              pair_dev_),
-        "abft_hip_spmv_dot_dev");
+  cg_vector *v = const_cast<cg_vector *>(vec);
+  const int off = comm_->rank() * slot_;
+  // rows that need nothing from the peers go beside the exchange, the others after it; the
+  // pair of launches equals one (include/abft_hip.h) and also leaves this shard's
+  // vec.result in pair_, for the dot that usually follows
+  exchange_begin(v);
+  check(abft_hip_spmv_dot_part_dev(ctx_, mat->handle, v->full, result->handle, off, pair_dev_, ABFT_PART_INTERIOR),
+        "abft_hip_spmv_dot_part_dev");
+  exchange_finish(v);
+  check(abft_hip_spmv_dot_part_dev(ctx_, mat->handle, v->full, result->handle, off, pair_dev_, ABFT_PART_BOUNDARY),
+        "abft_hip_spmv_dot_part_dev");
   fused_vec_ = vec;
   fused_res_ = result;
 }

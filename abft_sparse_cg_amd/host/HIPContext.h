@@ -78,6 +78,8 @@ private:
   void check(int rc, const char *what);
   void report_events(bool force);
   double reduce_scalar(abft_hip_vector *pair);
+  void exchange_begin(cg_vector *v);
+  void exchange_finish(cg_vector *v);
 
   abft_hip_ctx *ctx_;
   int format_;
@@ -87,6 +89,9 @@ private:
   Comm *comm_;
   std::vector<int> bounds_;      // row-block boundaries, size() + 1 entries
   int slot_, n_pad_, n_loc_, r0_; // slot length, padded vector length, this rank's rows [r0_, r0_ + n_loc_)
+  // all_need_[(src * size + dst) * 2 + {0,1}]: the window [lo, hi) of rank dst's slot that rank src reads
+  std::vector<int> all_need_;
+  bool use_windows_;             // exchange only those windows (banded matrices) instead of an all-gather
   abft_hip_vector *pair_;        // two doubles on the device: {partial sum, queued events}
   double *pair_dev_;             // ... their address (asked once: see abft_hip_vector_device_ptr)
   const cg_vector *fused_vec_;   // the last spmv also left vec.result in pair_ (until anything else runs)

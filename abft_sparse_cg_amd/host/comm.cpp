@@ -253,12 +253,86 @@ void Comm::barrier()
   allreduce_sum(&z, 1);
 }
 
+// Rank 0 relays: it first takes every other rank's outgoing pieces (a header of
+// {dst, bytes} pairs, then the payloads), then hands each rank what is addressed to it,
+// sources in ascending order -- the order in which the receiver lists its `in` pieces.
+void Comm::exchange(const std::vector<Piece> &out, const std::vector<Piece> &in)
+{
+  struct Item { int src, dst; std::vector<char> data; };
+  if (rank_ != 0)
+  {
+    unsigned long long n = out.size();
+    send_all(peers_[0], &n, sizeof(n));
+    for (size_t k = 0; k < out.size(); k++)
+    {
+      unsigned long long head[2] = {(unsigned long long)out[k].peer, out[k].bytes};
+      send_all(peers_[0], head, sizeof(head));
+      if (out[k].bytes) send_all(peers_[0], out[k].buf, out[k].bytes);
+    }
+    for (size_t k = 0; k < in.size(); k++)
+      if (in[k].bytes) recv_all(peers_[0], in[k].buf, in[k].bytes);
+    return;
+  }
+  std::vector<Item> items;
+  for (size_t k = 0; k < out.size(); k++)
+  {
+    Item it;
+    it.src = 0; it.dst = out[k].peer;
+    it.data.assign((const char *)out[k].buf, (const char *)out[k].buf + out[k].bytes);
+    items.push_back(it);
+  }
+  for (int r = 1; r < size_; r++)
+  {
+    unsigned long long n = 0;
+    recv_all(peers_[r], &n, sizeof(n));
+    for (unsigned long long k = 0; k < n; k++)
+    {
+      unsigned long long head[2];
+      recv_all(peers_[r], head, sizeof(head));
+      Item it;
+      it.src = r; it.dst = (int)head[0];
+      it.data.resize(head[1]);
+      if (head[1]) recv_all(peers_[r], it.data.data(), head[1]);
+      items.push_back(it);
+    }
+  }
+  // items are in ascending source order already; deliver per destination in that order
+  for (int d = 0; d < size_; d++)
+  {
+    size_t k_in = 0;
+    for (size_t i = 0; i < items.size(); i++)
+    {
+      if (items[i].dst != d) continue;
+      if (d == 0)
+      {
+        if (k_in >= in.size() || in[k_in].peer != items[i].src || in[k_in].bytes != items[i].data.size())
+        {
+          fprintf(stderr, "hip backend (comm): exchange pieces do not pair up\n");
+          exit(2);
+        }
+        if (in[k_in].bytes) memcpy(in[k_in].buf, items[i].data.data(), in[k_in].bytes);
+        k_in++;
+      }
+      else if (!items[i].data.empty())
+        send_all(peers_[d], items[i].data.data(), items[i].data.size());
+    }
+  }
+}
+
 void Comm::allreduce_sum_device(double *dev, int n, void *stream)
 {
   abft_rccl_allreduce_sum(rccl_, dev, n, stream);
 }
 
-void Comm::allgather_device(double *full, size_t slot, void *stream)
+void Comm::device_exchange_begin(void *stream) { abft_rccl_exchange_begin(rccl_, stream); }
+void Comm::device_exchange_finish(void *stream) { abft_rccl_exchange_finish(rccl_, stream); }
+
+void Comm::allgather_device(double *full, size_t slot)
 {
-  abft_rccl_allgather(rccl_, full, slot, rank_, stream);
+  abft_rccl_allgather(rccl_, full, slot, rank_);
+}
+
+void Comm::sendrecv_device(const std::vector<Piece> &out, const std::vector<Piece> &in)
+{
+  abft_rccl_sendrecv(rccl_, out, in);
 }

@@ -35,6 +35,11 @@ public:
                   std::vector<size_t> &sizes);                          // rank-ordered concatenation
   void allreduce_sum(double *v, int n);                                 // rank 0 adds in rank order
   void barrier();
+  // point-to-point pieces, relayed by rank 0: this rank sends out[k] to rank dst[k] and
+  // receives in[k] from rank src[k].  Every rank must list its pairs in ascending rank
+  // order and the two sides of a pair must agree on its size.
+  struct Piece { int peer; void *buf; size_t bytes; };
+  void exchange(const std::vector<Piece> &out, const std::vector<Piece> &in);
 
   // ---- device collectives, enqueued on `stream` (a hipStream_t) ----
   // call once the process has chosen its GPU; no-op when built without RCCL or ABFT_COMM=tcp
@@ -42,8 +47,15 @@ public:
   bool device_collectives() const { return rccl_ != NULL; }
   // v[0..n) += over ranks, in place, device memory
   void allreduce_sum_device(double *dev, int n, void *stream);
+  // Vector exchange beside compute: between begin and finish the two calls below run on a
+  // side stream that starts after everything enqueued on `stream` so far; finish makes
+  // `stream` wait for them.  Kernels enqueued on `stream` in between overlap the exchange.
+  void device_exchange_begin(void *stream);
+  void device_exchange_finish(void *stream);
   // slot `rank` of `full` (size() * slot doubles, device memory) is current; fill the others
-  void allgather_device(double *full, size_t slot, void *stream);
+  void allgather_device(double *full, size_t slot);
+  // windows: send out[k] (device memory, bytes a multiple of 8) to out[k].peer, receive in[k]
+  void sendrecv_device(const std::vector<Piece> &out, const std::vector<Piece> &in);
 
 private:
   Comm() : rank_(0), size_(1), local_rank_(0), listen_fd_(-1), rccl_(NULL) {}
@@ -61,4 +73,7 @@ private:
 void* abft_rccl_init(Comm *host, int device);
 void  abft_rccl_destroy(void *comm);
 void  abft_rccl_allreduce_sum(void *comm, double *dev, int n, void *stream);
-void  abft_rccl_allgather(void *comm, double *full, size_t slot, int rank, void *stream);
+void  abft_rccl_exchange_begin(void *comm, void *stream);
+void  abft_rccl_exchange_finish(void *comm, void *stream);
+void  abft_rccl_allgather(void *comm, double *full, size_t slot, int rank);
+void  abft_rccl_sendrecv(void *comm, const std::vector<Comm::Piece> &out, const std::vector<Comm::Piece> &in);

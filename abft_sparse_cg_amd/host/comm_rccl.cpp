@@ -19,40 +19,89 @@ static void check_nccl(ncclResult_t r, const char *what)
   exit(2);
 }
 
+// the communicator plus a side stream for exchanges that run beside compute
+struct RcclState
+{
+  ncclComm_t comm;
+  hipStream_t side;
+  hipEvent_t ready, done;
+};
+
+static void check_hip(hipError_t e, const char *what)
+{
+  if (e == hipSuccess)
+    return;
+  fflush(stdout);
+  fprintf(stderr, "hip backend (rccl): %s failed: %s\n", what, hipGetErrorString(e));
+  exit(2);
+}
+
 void* abft_rccl_init(Comm *host, int device)
 {
-  if (hipSetDevice(device) != hipSuccess)
-  {
-    fprintf(stderr, "hip backend (rccl): hipSetDevice(%d) failed\n", device);
-    exit(2);
-  }
+  check_hip(hipSetDevice(device), "hipSetDevice");
   ncclUniqueId id;
   if (host->rank() == 0)
     check_nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");
   host->bcast(&id, sizeof(id), 0);
-  ncclComm_t comm;
-  check_nccl(ncclCommInitRank(&comm, host->size(), id, host->rank()), "ncclCommInitRank");
-  return comm;
+  RcclState *st = new RcclState();
+  check_nccl(ncclCommInitRank(&st->comm, host->size(), id, host->rank()), "ncclCommInitRank");
+  check_hip(hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking), "hipStreamCreate");
+  check_hip(hipEventCreateWithFlags(&st->ready, hipEventDisableTiming), "hipEventCreate");
+  check_hip(hipEventCreateWithFlags(&st->done, hipEventDisableTiming), "hipEventCreate");
+  return st;
 }
 
-void abft_rccl_destroy(void *comm)
+void abft_rccl_destroy(void *p)
 {
-  if (comm)
-    ncclCommDestroy((ncclComm_t)comm);
+  RcclState *st = (RcclState *)p;
+  if (!st)
+    return;
+  (void)hipStreamSynchronize(st->side);
+  ncclCommDestroy(st->comm);
+  (void)hipEventDestroy(st->ready);
+  (void)hipEventDestroy(st->done);
+  (void)hipStreamDestroy(st->side);
+  delete st;
 }
 
-void abft_rccl_allreduce_sum(void *comm, double *dev, int n, void *stream)
+void abft_rccl_allreduce_sum(void *p, double *dev, int n, void *stream)
 {
-  check_nccl(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, (ncclComm_t)comm, (hipStream_t)stream),
-             "ncclAllReduce");
+  RcclState *st = (RcclState *)p;
+  check_nccl(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, st->comm, (hipStream_t)stream), "ncclAllReduce");
 }
 
-void abft_rccl_allgather(void *comm, double *full, size_t slot, int rank, void *stream)
+void abft_rccl_exchange_begin(void *p, void *stream)
 {
+  RcclState *st = (RcclState *)p;
+  check_hip(hipEventRecord(st->ready, (hipStream_t)stream), "hipEventRecord");
+  check_hip(hipStreamWaitEvent(st->side, st->ready, 0), "hipStreamWaitEvent");
+}
+
+void abft_rccl_exchange_finish(void *p, void *stream)
+{
+  RcclState *st = (RcclState *)p;
+  check_hip(hipEventRecord(st->done, st->side), "hipEventRecord");
+  check_hip(hipStreamWaitEvent((hipStream_t)stream, st->done, 0), "hipStreamWaitEvent");
+}
+
+void abft_rccl_allgather(void *p, double *full, size_t slot, int rank)
+{
+  RcclState *st = (RcclState *)p;
   // in place: this rank's contribution already sits in its slot of the receive buffer
-  check_nccl(ncclAllGather(full + (size_t)rank * slot, full, slot, ncclDouble, (ncclComm_t)comm,
-                           (hipStream_t)stream),
-             "ncclAllGather");
+  check_nccl(ncclAllGather(full + (size_t)rank * slot, full, slot, ncclDouble, st->comm, st->side), "ncclAllGather");
+}
+
+void abft_rccl_sendrecv(void *p, const std::vector<Comm::Piece> &out, const std::vector<Comm::Piece> &in)
+{
+  RcclState *st = (RcclState *)p;
+  check_nccl(ncclGroupStart(), "ncclGroupStart");
+  for (size_t k = 0; k < out.size(); k++)
+    check_nccl(ncclSend(out[k].buf, out[k].bytes / sizeof(double), ncclDouble, out[k].peer, st->comm, st->side),
+               "ncclSend");
+  for (size_t k = 0; k < in.size(); k++)
+    check_nccl(ncclRecv(in[k].buf, in[k].bytes / sizeof(double), ncclDouble, in[k].peer, st->comm, st->side),
+               "ncclRecv");
+  check_nccl(ncclGroupEnd(), "ncclGroupEnd");
 }
 
 #else
@@ -60,6 +109,9 @@ void abft_rccl_allgather(void *comm, double *full, size_t slot, int rank, void *
 void* abft_rccl_init(Comm *, int) { return NULL; }
 void  abft_rccl_destroy(void *) {}
 void  abft_rccl_allreduce_sum(void *, double *, int, void *) { abort(); }
-void  abft_rccl_allgather(void *, double *, size_t, int, void *) { abort(); }
+void  abft_rccl_exchange_begin(void *, void *) { abort(); }
+void  abft_rccl_exchange_finish(void *, void *) { abort(); }
+void  abft_rccl_allgather(void *, double *, size_t, int) { abort(); }
+void  abft_rccl_sendrecv(void *, const std::vector<Comm::Piece> &, const std::vector<Comm::Piece> &) { abort(); }
 
 #endif

@@ -56,6 +56,26 @@ int main()
   std::vector<double> got((size_t)n << 20);
   c->allgather(big.data(), big.size() * sizeof(double), got.data());
   for (int k = 0; k < n; k++) REQUIRE(got[((size_t)k << 20) + 12345] == (double)k);
+  // point-to-point pieces relayed by rank 0: rank s sends (d + 1) doubles of value 100 s + d to
+  // every rank d > s + 0 with (s + d) odd; pieces listed in ascending peer order on both sides
+  {
+    std::vector<std::vector<double> > obuf(n), ibuf(n);
+    std::vector<Comm::Piece> out, in;
+    for (int d = 0; d < n; d++)
+    {
+      if (d == r || ((r + d) & 1) == 0) continue;
+      obuf[d].assign(d + 1, 100.0 * r + d);
+      out.push_back(Comm::Piece{d, obuf[d].data(), obuf[d].size() * sizeof(double)});
+      ibuf[d].assign(r + 1, -1.0);
+      in.push_back(Comm::Piece{d, ibuf[d].data(), ibuf[d].size() * sizeof(double)});
+    }
+    c->exchange(out, in);
+    for (int s2 = 0; s2 < n; s2++)
+    {
+      if (s2 == r || ((r + s2) & 1) == 0) continue;
+      for (int i = 0; i <= r; i++) REQUIRE(ibuf[s2][i] == 100.0 * s2 + r);
+    }
+  }
   REQUIRE(!c->device_collectives());
   c->barrier();
   delete c;

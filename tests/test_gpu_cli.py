@@ -148,7 +148,9 @@ def test_python_driver_transcripts_match_reference(sharded):
 def run_ranks(world, args, opts=()):
     cmd = [os.path.join(HOST, "mgpu-run"), str(world)] + list(opts) + ["--", exe("csr")] + args
     # world 1: still the partitioned code path, with the device collectives on RCCL
-    env = dict(os.environ, ABFT_COMM_FORCE="1") if world == 1 else None
+    env = dict(os.environ, ABFT_HIP_VERBOSE="1")
+    if world == 1:
+        env["ABFT_COMM_FORCE"] = "1"
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
 
 
@@ -180,6 +182,14 @@ def test_cpp_driver_row_partitioned(world, opts, mode, flip):
     assert norm(rest1) == norm(restn)
     if flip:
         assert many.stdout.count("[ECC] corrected bit %s at index %s\n" % tuple(reversed(flip.split(":")))) == 1
+    # the partition each rank reports (ABFT_HIP_VERBOSE): the banded test matrix exchanges halo
+    # windows and multiplies its interior rows beside them; RCCL carries the one-rank job
+    notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
+    assert len(notes) == world
+    if world > 1:
+        assert all("exchange by windows over TCP" in l and "interior rows [0,0)" not in l for l in notes)
+    else:
+        assert "over RCCL" in notes[0]
 
 
 @pytest.mark.parametrize("world", [1, 3])
@@ -200,4 +210,6 @@ def test_cpp_driver_row_partitioned_synthetic_fixed_iterations():
     rrn, restn = split_transcript(many.stdout)
     assert len(rr1) == len(rrn) == 40
     assert all(abs(a - b) <= 1.01e-4 + 1e-9 * a for a, b in zip(rr1, rrn))
+    notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
+    assert len(notes) == 3 and all("exchange by all-gather" in l and "interior rows [0,0)" in l for l in notes)
     assert "ran for 40 iterations" in many.stdout
