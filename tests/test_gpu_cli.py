@@ -213,3 +213,12 @@ def test_cpp_driver_row_partitioned_synthetic_fixed_iterations():
     notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
     assert len(notes) == 3 and all("exchange by all-gather" in l and "interior rows [0,0)" in l for l in notes)
     assert "ran for 40 iterations" in many.stdout
+
+
+def test_run_tests_script_passes_row_partitioned():
+    """the reference's black-box acceptance phases (fault-free, sed detects, sec survives, secded
+    flags two flips) with every run split over two processes"""
+    launcher = "%s 2 --one-gpu -- %s" % (os.path.join(HOST, "mgpu-run"), exe("csr"))
+    p = subprocess.run([os.path.join(HOST, "run_tests"), launcher], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout
+    assert "FAILED" not in p.stdout and p.stdout.count("passed") >= 7 + 1 + 4 * 3 + 1
