@@ -23,6 +23,7 @@ is the one the north star names:
 The compute engine is a parameter: the product passes HipEngine (the C ABI);
 tests pass a CPU stand-in to exercise the partition/collective logic under gloo.
 """
+import ctypes as C
 import os
 import sys
 
@@ -108,6 +109,13 @@ class HipEngine:
 
     def calc_p_ratio(self, p, r, num, den):
         capi.check(self.L.abft_hip_calc_p_ratio_dev(self.ctx.h, p.h, r.h, num.device_ptr, den.device_ptr))
+
+    def read_pair(self, vec):
+        """{sum, events} at a 2-element device vector -> host, through the pinned slot the
+        host polls (a few microseconds; a copy + stream synchronise costs tens)"""
+        v, ev = C.c_double(), C.c_double()
+        capi.check(self.L.abft_hip_read_pair(self.ctx.h, vec.device_ptr, C.byref(v), C.byref(ev)))
+        return v.value, int(ev.value)
 
     def inject(self, A, index, bits):
         self.ctx.inject_at(A, index, bits)
@@ -280,8 +288,10 @@ class ShardedCG:
     def _allreduce_scalar(self):
         """-> (sum over ranks, total queued events); synchronises."""
         t = self.t_scal.cpu() if self.staged else self.t_scal
-        if self.G > 1:
+        if self.G > 1 or self.force_coll:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.staged and hasattr(self.e, "read_pair"):
+            return self.e.read_pair(self.scal)  # ordered behind the collective on the shared stream
         v = t.tolist()
         return v[0], int(v[1])
 
