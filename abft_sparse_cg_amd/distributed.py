@@ -361,7 +361,8 @@ class ShardedCG:
         host round trip per scalar would dominate).  Same kernels, same arithmetic
         (alpha = rr/pw and beta = rr_new/rr formed in fp64 on the device) as step().
 
-        graph (default: on, unless ABFT_CG_GRAPH=0 or the collectives are host-staged):
+        graph (default: on at world size 1, off across ranks; ABFT_CG_GRAPH=1 / 0 decides
+        otherwise; never with host-staged collectives):
         an iteration -- kernels, the two all-reduces and, in all-gather mode, the
         exchange -- is captured once into a hipGraph on the shared stream (two graphs:
         the rr / rr_new scalars swap roles every iteration) and replayed, so the host
@@ -377,7 +378,14 @@ class ShardedCG:
             vecs = [self.e.create_vector(2) for _ in range(3)]
             self._pipe = [(v, self.e.tensor(v)) for v in vecs]
         if graph is None:
-            graph = os.environ.get("ABFT_CG_GRAPH", "1") != "0"
+            # Default: replay at world size 1, where this stack is verified end to end; eager
+            # enqueue across ranks unless ABFT_CG_GRAPH=1 asks for replay there too.  (RCCL
+            # collectives inside a captured graph could only be exercised with one rank on the
+            # development box, and a captured point-to-point copy crashed this torch/RCCL pair;
+            # at 8 GPUs the eager enqueue costs about what the iteration takes on the GPU, so
+            # little is lost by not risking it unasked.)
+            env = os.environ.get("ABFT_CG_GRAPH")
+            graph = (self.G == 1) if env is None else env != "0"
         # (HIP-event brackets around kernels cannot be captured: profiling turns the graph off)
         graph = graph and not self.staged and hasattr(self.e, "tstream") and not self.e.ctx.prof_mask
         s0, s1, pw = self._pipe

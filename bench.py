@@ -203,7 +203,8 @@ def sharded(args):
     # run after the timed region instead of inside it
     replay = not args.host_scalars and bool(cg._graph)
     if not args.no_profile and not replay:
-        eng.ctx.profile(1 << capi.K_SPMV)
+        # sampled brackets (an odd stride: a shard with interior rows alternates two launches per SpMV)
+        eng.ctx.profile(1 << capi.K_SPMV, stride=5)
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
