@@ -5,6 +5,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <sys/socket.h>
+#include <sys/time.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -18,6 +19,8 @@ static void die(const char *what)
   fprintf(stderr, "hip backend (comm): %s: %s\n", what, strerror(errno));
   exit(2);
 }
+
+static const int kMagic = 0x41424654;  // "ABFT"
 
 static int env_int(const char *name, int fallback)
 {
@@ -87,13 +90,15 @@ void Comm::connect_star(const char *addr, int port)
       int fd = accept(listen_fd_, NULL, NULL);
       if (fd < 0) die("accept");
       setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      int who = -1;
-      recv_all(fd, &who, sizeof(who));
-      if (who <= 0 || who >= size_ || peers_[who] >= 0)
+      int hello[2] = {0, -1};  // {magic, rank}
+      recv_all(fd, hello, sizeof(hello));
+      const int who = hello[1];
+      if (hello[0] != kMagic || who <= 0 || who >= size_ || peers_[who] >= 0)
       {
-        fprintf(stderr, "hip backend (comm): unexpected rank %d at rendezvous\n", who);
+        fprintf(stderr, "hip backend (comm): unexpected peer at rendezvous (rank %d)\n", who);
         exit(2);
       }
+      send_all(fd, &kMagic, sizeof(kMagic));
       peers_[who] = fd;
     }
     return;
@@ -120,7 +125,22 @@ void Comm::connect_star(const char *addr, int port)
   }
   if (fd < 0) die("connect to rank 0");
   setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-  send_all(fd, &rank_, sizeof(rank_));
+  // introduce ourselves and make sure it is rank 0 of this job that answered (not some other
+  // service on MASTER_PORT): the reply must arrive, and be the magic word, within a minute
+  int hello[2] = {kMagic, rank_};
+  send_all(fd, hello, sizeof(hello));
+  timeval tv;
+  tv.tv_sec = 60; tv.tv_usec = 0;
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+  int ack = 0;
+  recv_all(fd, &ack, sizeof(ack));
+  if (ack != kMagic)
+  {
+    fprintf(stderr, "hip backend (comm): MASTER_PORT %d answered, but not as rank 0 of this job\n", port);
+    exit(2);
+  }
+  tv.tv_sec = 0;
+  setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
   peers_.assign(1, fd);
 }
 

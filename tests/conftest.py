@@ -12,3 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "ref: needs the reference build under oracle/_ref")
+
+
+def pytest_collection_modifyitems(config, items):
+    # no test may hang the run: with pytest-timeout present every test gets a ceiling (a stuck
+    # one then fails with the stacks of all threads instead of silencing the whole session)
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))

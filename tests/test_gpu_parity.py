@@ -608,14 +608,22 @@ def test_deferred_x_update_is_transparent(amd):
         ora_calc_p(p2, r2, beta)
         assert bits_equal(ctx.download(x), x2) and bits_equal(ctx.download(p), p2)
 
-        # (6) a vector whose device address was handed out is never deferred
+        # (6) a vector whose device address was handed out is never deferred: read it back
+        # with the HIP runtime directly -- no library call in between that could apply a
+        # pending update
         x, r, p, w, q = fresh()
-        assert x.device_ptr
+        ptr = x.device_ptr
+        assert ptr
         ctx.calc_xr(x, r, p, w, alpha)
-        import torch
-        torch.cuda.synchronize()  # (not ctx.synchronize(): a library call would apply a pending update)
-        from abft_sparse_cg_amd.distributed import _DevMem
-        seen = torch.as_tensor(_DevMem(x.device_ptr, n), device="cuda:0").cpu().numpy()
+        hip = ctypes.CDLL(None)  # the runtime libabft_hip.so is bound to (loaded RTLD_GLOBAL)
+        if not hasattr(hip, "hipMemcpy"):
+            hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipDeviceSynchronize.restype = ctypes.c_int
+        hip.hipMemcpy.restype = ctypes.c_int
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipDeviceSynchronize() == 0
+        seen = np.empty(n)
+        assert hip.hipMemcpy(seen.ctypes.data, ptr, n * 8, 2) == 0  # hipMemcpyDeviceToHost
         assert bits_equal(seen, xr)
     finally:
         ctx.close()
