@@ -68,9 +68,20 @@ class HIPContext:
         self.h = h
         self.event_log = []
         self.prof_mask = 0
+        self._live = []  # matrices and vectors not yet destroyed, in creation order
 
     def close(self):
+        """destroy what the caller left behind (views before their parents: reverse creation
+        order), then the context"""
         if self.h:
+            for obj in reversed(self._live):
+                if obj.h:
+                    if isinstance(obj, Matrix):
+                        self.L.abft_hip_matrix_destroy(obj.h)
+                    else:
+                        self.L.abft_hip_vector_destroy(obj.h)
+                    obj.h = None
+            self._live = []
             self.L.abft_hip_shutdown(self.h)
             self.h = None
 
@@ -92,12 +103,15 @@ class HIPContext:
         check(self.L.abft_hip_matrix_create_shard(
             self.h, self.fmt, self.mode_id, columns.ctypes.data_as(capi.u32p), rows.ctypes.data_as(capi.u32p),
             values.ctypes.data_as(capi.f64p), N, n_in, nnz, index_base, C.byref(h)))
-        return Matrix(self, h, self.fmt, self.mode, N, n_in, nnz)
+        m = Matrix(self, h, self.fmt, self.mode, N, n_in, nnz)
+        self._live.append(m)
+        return m
 
     def destroy_matrix(self, mat):
         self._drain()
         check(self.L.abft_hip_matrix_destroy(mat.h))
         mat.h = None
+        self._live = [o for o in self._live if o is not mat]
 
     def stored_words(self, mat):
         """(nnz, 3|4) uint32 image of the stored elements in the caller's order."""
@@ -122,16 +136,21 @@ class HIPContext:
     def create_vector(self, N):
         h = C.c_void_p()
         check(self.L.abft_hip_vector_create(self.h, N, C.byref(h)))
-        return Vector(self, h, N)
+        v = Vector(self, h, N)
+        self._live.append(v)
+        return v
 
     def view_vector(self, parent, offset, N):
         h = C.c_void_p()
         check(self.L.abft_hip_vector_view(parent.h, offset, N, C.byref(h)))
-        return Vector(self, h, N)
+        v = Vector(self, h, N)
+        self._live.append(v)
+        return v
 
     def destroy_vector(self, vec):
         check(self.L.abft_hip_vector_destroy(vec.h))
         vec.h = None
+        self._live = [o for o in self._live if o is not vec]
 
     def map_vector(self, v):
         """-> numpy view of the pinned staging buffer (valid until unmap)."""
