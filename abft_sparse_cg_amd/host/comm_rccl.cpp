@@ -5,6 +5,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #ifdef ABFT_WITH_RCCL
 #include <hip/hip_runtime_api.h>
@@ -39,6 +40,10 @@ static void check_hip(hipError_t e, const char *what)
 void* abft_rccl_init(Comm *host, int device)
 {
   check_hip(hipSetDevice(device), "hipSetDevice");
+  // RCCL prints its version banner on stdout at this level; stdout is the driver's transcript
+  if (const char *dbg = getenv("NCCL_DEBUG"))
+    if (!strcmp(dbg, "VERSION"))
+      unsetenv("NCCL_DEBUG");
   ncclUniqueId id;
   if (host->rank() == 0)
     check_nccl(ncclGetUniqueId(&id), "ncclGetUniqueId");

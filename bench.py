@@ -175,6 +175,8 @@ def sharded(args):
     if args.fmt != "csr":
         raise SystemExit("the row-partitioned solver shards CSR; COO runs on one GPU")
     torch.cuda.set_device(local)
+    if os.environ.get("NCCL_DEBUG") == "VERSION":
+        os.environ.pop("NCCL_DEBUG")  # RCCL's version banner goes to stdout, which carries the one JSON line
     dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     n = generators.dim(args.spec)
     bounds = generators.partition(args.spec, world)
