@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign on the GPU: HIP path (through the C ABI) against the CPU
+oracle on random matrices, modes, layouts and bit flips -- stored words, SpMV results
+(bit for bit, two passes: corrections persist), event streams, and SpMV-in-two-parts.
+
+    python tools/fuzz_parity.py [seconds] [first_seed]
+
+A checker like the tests (it loads oracle/ through tests/_oracle.py); prints one line per
+failure with the seed that reproduces it, and a summary."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _oracle import COO, CSR, MODES, OracleMatrix  # noqa: E402
+
+import abft_sparse_cg_amd as amd  # noqa: E402
+from abft_sparse_cg_amd import capi  # noqa: E402
+
+NBITS = {CSR: 96, COO: 128}
+FNAME = {CSR: "csr", COO: "coo"}
+
+
+def matrix(rng):
+    n = int(rng.choice([1, 2, 7, 64, 300, 1000, 3000, 6000]))
+    kind = rng.integers(0, 3)
+    rows, cols = [], []
+    for r in range(n):
+        if kind == 0:
+            k = int(rng.choice([0, 1, 2, 3, 5, 8]))
+        elif kind == 1:
+            k = int(rng.choice([0, 0, 1, 4, 30, 200])) if rng.random() < 0.98 else int(rng.integers(1000, 4000))
+        else:
+            k = int(rng.integers(0, 12))
+        k = min(k, n)
+        c = np.sort(rng.choice(n, size=k, replace=False))
+        rows.append(np.full(k, r))
+        cols.append(c)
+    rows = np.concatenate(rows) if rows else np.zeros(0)
+    cols = np.concatenate(cols) if cols else np.zeros(0)
+    vals = rng.standard_normal(len(rows)) * 10.0 ** rng.integers(-3, 4, size=len(rows))
+    return cols.astype(np.uint32), rows.astype(np.uint32), vals, n
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    cols, rows, vals, n = matrix(rng)
+    nnz = len(vals)
+    fmt = CSR if rng.random() < 0.6 else COO
+    mode = str(rng.choice(MODES))
+    layout = str(rng.choice(["stream", "panels", "auto"]))
+    os.environ["ABFT_HIP_LAYOUT"] = layout
+    os.environ["ABFT_HIP_PANEL_WIDTH"] = str(int(rng.choice([16, 100, 257, 4096])))
+    os.environ["ABFT_HIP_PANEL_CHUNK"] = str(int(rng.choice([0, 1, 2, 3])))
+    flips = []
+    if nnz and mode not in ("none", "constraints"):
+        for _ in range(int(rng.integers(0, 4))):
+            idx = int(rng.integers(0, nnz))
+            nb = 1 if rng.random() < 0.7 else 2
+            flips.append((idx, [int(b) for b in rng.choice(NBITS[fmt], size=nb, replace=False)]))
+    x = rng.standard_normal(n)
+    seen = []
+    o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+    ctx = amd.HIPContext(mode, FNAME[fmt], on_event=lambda ev, fatal: seen.append((list(ev), fatal)))
+    what = "seed %d: n=%d nnz=%d %s %s layout=%s flips=%s" % (seed, n, nnz, FNAME[fmt], mode, layout, flips)
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, nnz)
+        if not np.array_equal(ctx.stored_words(A), o.stored_words()):
+            return what + " : stored words differ"
+        split = fmt == CSR and rng.random() < 0.5 and n > 2
+        if split:
+            lo = int(rng.integers(0, n))
+            ctx.set_interior(A, lo, int(rng.integers(lo, n + 1)))
+        for i, b in flips:
+            o.inject(i, b)
+            ctx.inject_at(A, i, b)
+        vx, vy = ctx.create_vector(n), ctx.create_vector(n)
+        ctx.upload(vx, x)
+        for p in range(2):
+            ctx.upload(vy, np.full(n, np.nan))
+            seen.clear()
+            if split:
+                ctx.spmv(A, vx, vy, capi.PART_INTERIOR)
+                ctx.spmv(A, vx, vy, capi.PART_BOUNDARY)
+            else:
+                ctx.spmv(A, vx, vy)
+            y = ctx.download(vy)
+            ev = [e for evs, _ in seen for e in evs]
+            fatal = any(f for _, f in seen)
+            want = o.spmv(x)
+            oev, ofatal = o.events()
+            # COO, a column field silently corrupted (undetectable multi-bit damage): the reference
+            # scatters into the corrupted row, the HIP path keeps the element in its group
+            # (deliberate difference no. 5) -- y is not comparable then
+            moved = fmt == COO and any((int(o.stored_words()[i][0]) & 0xFFFFFF) != int(cols[i]) for i, _ in flips)
+            if (sorted(ev), fatal) != (sorted(oev), ofatal) and not (fatal and ofatal and ev[:1] == oev[:1]):
+                return what + " : pass %d events %s fatal=%s, oracle %s fatal=%s" % (p, ev, fatal, oev, ofatal)
+            if fatal:
+                return None  # the reference stops here
+            if not moved and not bits_equal(y, want):
+                bad = np.nonzero(np.asarray(y).view(np.uint64) != np.asarray(want).view(np.uint64))[0]
+                return what + " : pass %d y differs at rows %s" % (p, bad[:5])
+        return None
+    finally:
+        ctx.close()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, done, bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        try:
+            msg = one_case(seed)
+        except Exception as e:  # noqa: BLE001
+            msg = "seed %d: exception %r" % (seed, e)
+        if msg:
+            bad += 1
+            print("FAIL " + msg, flush=True)
+        done += 1
+        seed += 1
+        if done % 50 == 0:
+            print("... %d cases, %d failures, %.0f s" % (done, bad, time.time() - t0), flush=True)
+    print("fuzz: %d cases, %d failures" % (done, bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
