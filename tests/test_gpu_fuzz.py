@@ -18,3 +18,13 @@ def test_short_fuzz_campaign():
                        capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
     assert "0 failures" in p.stdout
+
+
+def test_short_call_sequence_campaign():
+    """tools/fuzz_sequence.py: random interleavings of spmv / dot / calc_xr / calc_p / copy /
+    map / unmap against a numpy model -- the fused dot and the deferred x update must never
+    show (vectors bit-identical whenever read)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_sequence.py"), "15", "500000"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1000:]
+    assert " 0 failures" in p.stdout

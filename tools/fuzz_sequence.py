@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Randomised call sequences through the C ABI against a numpy model: spmv, dot, calc_xr,
+calc_p, copy_vector, map/unmap in random order on a handful of vectors.  What is under test
+is the state the library keeps across calls -- the dot fused into the SpMV and the x update
+deferred from calc_xr into calc_p must be invisible under every interleaving: vectors
+bit-identical to the model whenever they are read, scalars within the reductions' tolerance.
+
+    python tools/fuzz_sequence.py [seconds] [first_seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from _oracle import CSR, OracleMatrix, laplace5, random_spd  # noqa: E402
+
+import abft_sparse_cg_amd as amd  # noqa: E402
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint64), np.asarray(b).view(np.uint64))
+
+
+def one_case(seed):
+    rng = np.random.default_rng(seed)
+    if rng.random() < 0.5:
+        g = int(rng.integers(3, 40))
+        cols, rows, vals, n = laplace5(g, int(rng.integers(3, 40)))
+    else:
+        cols, rows, vals, n = random_spd(int(rng.choice([50, 300, 2000])), int(rng.integers(2, 12)), seed=seed)
+    mode = str(rng.choice(["none", "secded"]))
+    o = OracleMatrix(CSR, mode, cols, rows, vals, n)
+    ctx = amd.HIPContext(mode, "csr")
+    NV = 6
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        dev = [ctx.create_vector(n) for _ in range(NV)]
+        model = [rng.standard_normal(n) for _ in range(NV)]
+        for d, m in zip(dev, model):
+            ctx.upload(d, m)
+        trace = []
+        for step in range(int(rng.integers(10, 60))):
+            op = str(rng.choice(["spmv", "dot", "calc_xr", "calc_p", "copy", "download", "upload", "cgstep"]))
+            ids = [int(i) for i in rng.permutation(NV)]
+            trace.append((op, ids[:4]))
+            if op == "spmv":
+                a, b = ids[:2]
+                ctx.spmv(A, dev[a], dev[b])
+                model[b] = o.spmv(model[a])
+            elif op == "dot":
+                a, b = (ids[0], ids[1]) if rng.random() < 0.8 else (ids[0], ids[0])
+                got = ctx.dot(dev[a], dev[b])
+                want = float(np.dot(model[a], model[b]))
+                tol = 1e-12 * float(np.abs(model[a] * model[b]).sum()) + 1e-300
+                if not abs(got - want) <= tol:
+                    return "seed %d step %d %s: dot %r vs %r" % (seed, step, trace[-6:], got, want)
+            elif op in ("calc_xr", "cgstep"):
+                x, r, p, w = ids[:4]
+                alpha = float(rng.uniform(-0.5, 0.5))
+                if op == "cgstep":  # the CG order: spmv, dot, calc_xr, calc_p back to back
+                    ctx.spmv(A, dev[p], dev[w])
+                    model[w] = o.spmv(model[p])
+                    pw = ctx.dot(dev[p], dev[w])
+                    want = float(np.dot(model[p], model[w]))
+                    if not abs(pw - want) <= 1e-12 * float(np.abs(model[p] * model[w]).sum()) + 1e-300:
+                        return "seed %d step %d %s: fused dot %r vs %r" % (seed, step, trace[-6:], pw, want)
+                got = ctx.calc_xr(dev[x], dev[r], dev[p], dev[w], alpha)
+                model[x] = model[x] + alpha * model[p]
+                model[r] = model[r] - alpha * model[w]
+                want = float(np.dot(model[r], model[r]))
+                if not abs(got - want) <= 1e-12 * want + 1e-300:
+                    return "seed %d step %d %s: calc_xr %r vs %r" % (seed, step, trace[-6:], got, want)
+                if op == "cgstep":
+                    beta = float(rng.uniform(-0.5, 0.5))
+                    ctx.calc_p(dev[p], dev[r], beta)
+                    model[p] = model[r] + beta * model[p]
+            elif op == "calc_p":
+                p, r = ids[:2]
+                beta = float(rng.uniform(-0.9, 0.9))
+                ctx.calc_p(dev[p], dev[r], beta)
+                model[p] = model[r] + beta * model[p]
+            elif op == "copy":
+                a, b = ids[:2]
+                ctx.copy_vector(dev[a], dev[b])
+                model[a] = model[b].copy()
+            elif op == "upload":
+                a = ids[0]
+                model[a] = rng.standard_normal(n)
+                ctx.upload(dev[a], model[a])
+            else:
+                a = ids[0]
+                if not bits_equal(ctx.download(dev[a]), model[a]):
+                    return "seed %d step %d %s: vector %d differs" % (seed, step, trace[-8:], a)
+            # keep magnitudes bounded
+            for k in range(NV):
+                if not np.isfinite(model[k]).all() or np.abs(model[k]).max() > 1e100:
+                    model[k] = rng.standard_normal(n)
+                    ctx.upload(dev[k], model[k])
+        for k in range(NV):
+            if not bits_equal(ctx.download(dev[k]), model[k]):
+                return "seed %d end %s: vector %d differs" % (seed, trace[-8:], k)
+        return None
+    finally:
+        ctx.close()
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    t0, done, bad = time.time(), 0, 0
+    while time.time() - t0 < budget:
+        try:
+            msg = one_case(seed)
+        except Exception as e:  # noqa: BLE001
+            msg = "seed %d: exception %r" % (seed, e)
+        if msg:
+            bad += 1
+            print("FAIL " + msg, flush=True)
+        done += 1
+        seed += 1
+    print("fuzz_sequence: %d sequences, %d failures" % (done, bad), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
