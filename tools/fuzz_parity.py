@@ -26,20 +26,30 @@ FNAME = {CSR: "csr", COO: "coo"}
 
 
 def matrix(rng):
-    n = int(rng.choice([1, 2, 7, 64, 300, 1000, 3000, 6000]))
+    sizes = [1, 2, 7, 64, 300, 1000, 3000, 6000]
+    if os.environ.get("ABFT_FUZZ_BIG") == "1":  # fewer, larger cases (several row blocks per XCD, long sweeps)
+        sizes = [20000, 60000, 150000]
+    n = int(rng.choice(sizes))
     kind = rng.integers(0, 3)
     rows, cols = [], []
-    for r in range(n):
-        if kind == 0:
-            k = int(rng.choice([0, 1, 2, 3, 5, 8]))
-        elif kind == 1:
-            k = int(rng.choice([0, 0, 1, 4, 30, 200])) if rng.random() < 0.98 else int(rng.integers(1000, 4000))
-        else:
-            k = int(rng.integers(0, 12))
-        k = min(k, n)
-        c = np.sort(rng.choice(n, size=k, replace=False))
-        rows.append(np.full(k, r))
-        cols.append(c)
+    if n >= 20000:  # vectorised draw for the large cases: k entries per row, duplicates removed
+        k = rng.choice([0, 1, 2, 3, 5, 8, 30], size=n)
+        r = np.repeat(np.arange(n), k)
+        c = rng.integers(0, n, size=len(r))
+        key = np.unique(r.astype(np.int64) * n + c)
+        rows, cols = [key // n], [key % n]
+    else:
+        for r in range(n):
+            if kind == 0:
+                k = int(rng.choice([0, 1, 2, 3, 5, 8]))
+            elif kind == 1:
+                k = int(rng.choice([0, 0, 1, 4, 30, 200])) if rng.random() < 0.98 else int(rng.integers(1000, 4000))
+            else:
+                k = int(rng.integers(0, 12))
+            k = min(k, n)
+            c = np.sort(rng.choice(n, size=k, replace=False))
+            rows.append(np.full(k, r))
+            cols.append(c)
     rows = np.concatenate(rows) if rows else np.zeros(0)
     cols = np.concatenate(cols) if cols else np.zeros(0)
     vals = rng.standard_normal(len(rows)) * 10.0 ** rng.integers(-3, 4, size=len(rows))
