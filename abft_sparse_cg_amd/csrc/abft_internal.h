@@ -126,7 +126,8 @@ struct ReduceOut {
 // Cross-call fusion: an SpMV on a square matrix also forms
 // sum_row vec[row] * result[row], so the dot(p, w) the CG loop asks for right
 // after spmv(A, p, w) needs no pass over the vectors.  Each block leaves one
-// partial; a one-block kernel behind the SpMV folds them in a fixed order and
+// partial; a small kernel behind the SpMV (one workgroup, or several for many partials:
+// launch_fuse_finalize) folds them in a fixed order and
 // publishes the scalar like a reduction does.  `partials` belongs to the matrix.
 struct FuseOut {
   double *partials;  // one per SpMV workgroup

@@ -204,7 +204,8 @@ hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s
 // sum vec[row]*result[row].  The block leaves one partial with a plain store
 // and exits -- nothing here waits on memory.  (An in-kernel ticket protocol
 // was measured first: the storing lane's drain + returning atomic kept every
-// block resident ~2x longer and cost 75 us per SpMV.)  fuse_finalize_kernel,
+// block resident ~2x longer and cost 75 us per SpMV.)  A fold kernel (fuse_finalize_kernel
+// below, or fold_partials_kernel when there are many partials),
 // launched behind the SpMV on the same stream, folds the partials in a fixed
 // order and publishes the scalar.
 __device__ __forceinline__ void fused_dot_finish(double dsum, const FuseOut &f, uint32_t slot) {

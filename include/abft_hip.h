@@ -255,7 +255,7 @@ typedef enum {
  * two event records per launch, so measure throughput with only the kernel of
  * interest enabled.  abft_hip_profile_read synchronises and returns the summed
  * device time (ms) and launch count since the last reset.  With the fused dot
- * (spmv on a square matrix), ABFT_K_DOT times the one-block fold that is left
+ * (spmv on a square matrix), ABFT_K_DOT times the small fold kernel that is left
  * of dot(p, w).  abft_hip_profile_stride(n) brackets only every n-th launch of an
  * enabled kernel (default 1): a sampled average at 1/n of the cost. */
 int abft_hip_profile_enable(abft_hip_ctx *ctx, int mask);
