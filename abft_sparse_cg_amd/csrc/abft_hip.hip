@@ -317,6 +317,21 @@ static void cut_blocks(const uint32_t *ptr, uint32_t n, uint32_t tile, bool alig
   }
 }
 
+// Flag the CSR row blocks whose rows all have the same length -- bit 31 of the end row:
+// the kernel then derives each row's range from the block descriptor alone and never reads
+// the row pointers (banded matrices: nearly every block; measured 151 -> 138 us on config
+// 2's SpMV, 143 -> 134 us in secded; the same shortcut in the COO kernel was 4 % slower).
+static void flag_uniform_blocks(const uint32_t *ptr, uint32_t tile, std::vector<uint4> &blk) {
+  for (uint4 &b : blk) {
+    const uint32_t nseg = b.y - b.x;
+    if (nseg < 2 || b.w - b.z > tile || nseg > (uint32_t)ABFT_BLOCK) continue;
+    const uint32_t len = ptr[b.x + 1] - ptr[b.x];
+    bool same = len > 0 && (b.w - b.z) == len * nseg;
+    for (uint32_t r = b.x; same && r < b.y; r++) same = ptr[r + 1] - ptr[r] == len;
+    if (same) b.y |= 0x80000000u;
+  }
+}
+
 // ---- panel layout planning (host) ----------------------------------------------
 
 struct PanelBuild {
@@ -415,6 +430,7 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   while (next <= (uint32_t)n_out) rowptr[next++] = (uint32_t)nnz;
   std::vector<uint4> blk;
   cut_blocks(rowptr.data(), (uint32_t)n_out, ABFT_CSR_TILE, true, blk);
+  flag_uniform_blocks(rowptr.data(), ABFT_CSR_TILE, blk);
 
   CsrDev &A = m->csr;
   A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
@@ -619,7 +635,7 @@ extern "C" int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, in
   uint32_t lo = 0;
   while (lo < b.size() && b[lo].x < (uint32_t)row_lo) lo++;  // first tile starting at or after row_lo
   uint32_t hi = lo;
-  while (hi < b.size() && b[hi].y <= (uint32_t)row_hi) hi++;  // tiles that end at or before row_hi
+  while (hi < b.size() && (b[hi].y & 0x7fffffffu) <= (uint32_t)row_hi) hi++;  // tiles that end at or before row_hi
   if (hi > lo) { mat->t_lo = lo; mat->t_hi = hi; }
   return ABFT_OK;
 }

@@ -75,6 +75,9 @@ struct CooDev {
 #ifndef ABFT_CFG_SCHED_BARRIER
 #define ABFT_CFG_SCHED_BARRIER 1
 #endif
+#ifndef ABFT_CFG_UNIFORM_ROWS
+#define ABFT_CFG_UNIFORM_ROWS 1  // row blocks of equal-length rows are flagged and skip the row-pointer loads
+#endif
 #ifndef ABFT_CFG_NT
 #define ABFT_CFG_NT 1  // stream cols/vals with the non-temporal hint
 #endif

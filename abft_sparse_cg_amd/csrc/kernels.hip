@@ -420,7 +420,10 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
   const uint32_t b = xcd_tile(blockIdx.x, span.count);
   const uint32_t t = span.first + b + (b >= span.cut ? span.skip : 0u);
   const uint4 desc = A.blk[t];  // one scalar load instead of two dependent pairs
-  const uint32_t row0 = desc.x, row1 = desc.y, e0 = desc.z, e1 = desc.w;
+  // bit 31 of the second word: every row of this block has the same length (banded
+  // matrices: nearly all blocks), so the row pointers need not be read at all
+  const bool uniform = ABFT_CFG_UNIFORM_ROWS && MODE != MODE_CONSTRAINTS && (desc.y >> 31) != 0u;
+  const uint32_t row0 = desc.x, row1 = desc.y & 0x7fffffffu, e0 = desc.z, e1 = desc.w;
   const uint32_t base = e0 & ~1u;
   double dsum = 0.0;  // FUSE: this thread's share of sum x[row] * y[row]
 
@@ -430,7 +433,12 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
     uint32_t rs = 0, re = 0;
     double xr = 0.0;
     if (r < row1) {
-      rs = A.rowptr[r]; re = A.rowptr[r + 1];
+      if (uniform) {
+        const uint32_t len = (e1 - e0) / (row1 - row0);  // scalar
+        rs = e0 + len * threadIdx.x; re = rs + len;
+      } else {
+        rs = A.rowptr[r]; re = A.rowptr[r + 1];
+      }
       if (FUSE) xr = x[fuse.x_off + r];
     }
     csr_stage<MODE, EPT>(A, x, ev, base, e0, e1, s_prod, s_col);
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
     uint32_t gs = 0, ge = 0;
     double xg = 0.0;
     if (g < g1) {
-      gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1];
+      gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1];  // (the uniform-block shortcut of the CSR kernel measured 4 % slower here)
       if (FUSE) xg = x[fuse.x_off + g];
     }
     coo_stage<MODE, EPT>(A, x, ev, e0, e1, s_prod);
