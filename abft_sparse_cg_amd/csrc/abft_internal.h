@@ -93,7 +93,10 @@ constexpr int ABFT_CSR_EPT = ABFT_CFG_CSR_EPT;           // elements per thread 
 constexpr int ABFT_CSR_TILE = ABFT_BLOCK * ABFT_CSR_EPT;  // nnz staged per block
 constexpr int ABFT_COO_EPT = ABFT_CFG_COO_EPT;
 constexpr int ABFT_COO_TILE = ABFT_BLOCK * ABFT_COO_EPT;
-constexpr int ABFT_MAX_PARTIALS = 2048;  // reduction blocks (256 CUs x 8)
+#ifndef ABFT_CFG_MAX_PARTIALS
+#define ABFT_CFG_MAX_PARTIALS 2048  // 256 CUs x 8 (1024: calc_px 7 % slower; 4096: calc_r 10 % slower)
+#endif
+constexpr int ABFT_MAX_PARTIALS = ABFT_CFG_MAX_PARTIALS;  // reduction blocks
 constexpr int ABFT_TICKET_GROUP = 32;    // blocks per first-level arrival counter
 constexpr int ABFT_TICKET_WORDS = 1 + ABFT_MAX_PARTIALS / ABFT_TICKET_GROUP;  // [0] top, [1..] groups
 
