@@ -223,6 +223,33 @@ class ShardedCG:
         engine.upload(self.p_full, np.zeros(self.n_pad))
         self.events = []
         self._p2p_cache = {}
+        if self.use_windows and self._windows_by_alltoall and not self._alltoall_selftest():
+            self._windows_by_alltoall = False  # point-to-point copies instead
+
+    def _alltoall_selftest(self):
+        """One trial window exchange through all_to_all on a scratch vector (slot g filled with
+        g + 1): every window received must carry its sender's number, on every rank.  A wrong
+        answer or an exception on any rank sends all ranks to batch_isend_irecv."""
+        ok = 1.0
+        try:
+            t = torch.zeros(self.n_pad, dtype=torch.float64, device=self.t_full.device)
+            S, me = self.slot, self.rank
+            t[me * S:me * S + self.n_loc] = float(me + 1)
+            for req in self._window_exchange(t, None):
+                req.wait()
+            for g in range(self.G):
+                lo, hi = self.need[g] if g != me else (0, 0)
+                if hi > lo and not bool((t[g * S + lo:g * S + hi] == float(g + 1)).all()):
+                    ok = 0.0
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("abft: all_to_all window exchange failed its self-test (%s)\n" % exc)
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64, device=self.t_full.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        good = bool(flag.item() > 0.5)
+        if not good and self.rank == 0:
+            sys.stderr.write("abft: halo windows by batch_isend_irecv (all_to_all self-test failed)\n")
+        return good
 
     # ---- collectives -------------------------------------------------------
     def exchange(self, full_vec_tensor):

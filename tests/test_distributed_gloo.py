@@ -154,6 +154,10 @@ def _worker(rank, world, port, case, q):
         nnz_before = int(np.argmax(m)) if m.any() else 0
         eng = OracleEngine(mode)
         cg = ShardedCG(eng, cols[m], rows[m], vals[m], bounds, nnz_before, mode)
+        if cg.use_windows:
+            # the trial exchange the nccl path runs before trusting all_to_all (here over the
+            # point-to-point form of the same window lists): every window carries its sender's number
+            assert cg._alltoall_selftest()
         b = rhs(n, 1)
         cg.set_rhs(b[r0:r1])
         if flip is not None:
