@@ -10,7 +10,7 @@
 
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
-    r0_(0), use_windows_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL)
+    r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL)
 {
   int device = comm_ ? comm_->local_rank() : 0;
   if (const char *env = getenv("ABFT_HIP_DEVICE"))
@@ -217,10 +217,21 @@ cg_matrix* HIPContextBase::create_matrix(const uint32_t *columns, const uint32_t
   const bool interior = best_hi - best_lo >= std::max(n_loc_ / 4, 1);
   if (interior)
     check(abft_hip_matrix_set_interior(M->handle, best_lo, best_hi), "abft_hip_matrix_set_interior");
+  // ... which is worth its two stream hand-offs (~20 us) only for a long exchange; a halo of a few
+  // KB goes on the compute stream in front of a single SpMV launch (ABFT_CG_OVERLAP_BYTES decides)
+  long long incoming = 0;
+  if (use_windows_)
+    for (int g = 0; g < G; g++) incoming += need[2 * g + 1] - need[2 * g];
+  else
+    incoming = (long long)(G - 1) * slot_;
+  long long least = 2ll << 20;
+  if (const char *env = getenv("ABFT_CG_OVERLAP_BYTES")) least = atoll(env);
+  overlap_ = interior && incoming * 8 >= least;
   if (getenv("ABFT_HIP_VERBOSE"))
     fprintf(stderr, "hip backend: rank %d of %d: rows [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
-            "interior rows [%d,%d)\n", me, G, r0_, r0_ + n_loc_, cnt, e0, use_windows_ ? "windows" : "all-gather",
-            comm_->device_collectives() ? "RCCL" : "TCP", interior ? best_lo : 0, interior ? best_hi : 0);
+            "interior rows [%d,%d)%s\n", me, G, r0_, r0_ + n_loc_, cnt, e0, use_windows_ ? "windows" : "all-gather",
+            comm_->device_collectives() ? "RCCL" : "TCP", interior ? best_lo : 0, interior ? best_hi : 0,
+            overlap_ ? " beside the exchange" : "");
   return M;
 }
 
@@ -357,7 +368,7 @@ void HIPContextBase::exchange_begin(cg_vector *v)
   const int G = comm_->size(), me = comm_->rank();
   if (!v->full_dev)
     v->full_dev = (double *)abft_hip_vector_device_ptr(v->full);
-  comm_->device_exchange_begin(abft_hip_get_stream(ctx_));
+  comm_->device_exchange_begin(abft_hip_get_stream(ctx_), overlap_);
   if (!use_windows_)
   {
     comm_->allgather_device(v->full_dev, (size_t)slot_);
@@ -421,10 +432,12 @@ void HIPContextBase::spmv(const cg_matrix *mat, const cg_vector *vec, cg_vector 
   // pair of launches equals one (include/abft_hip.h) and also leaves this shard's
   // vec.result in pair_, for the dot that usually follows
   exchange_begin(v);
-  check(abft_hip_spmv_dot_part_dev(ctx_, mat->handle, v->full, result->handle, off, pair_dev_, ABFT_PART_INTERIOR),
-        "abft_hip_spmv_dot_part_dev");
+  if (overlap_)
+    check(abft_hip_spmv_dot_part_dev(ctx_, mat->handle, v->full, result->handle, off, pair_dev_, ABFT_PART_INTERIOR),
+          "abft_hip_spmv_dot_part_dev");
   exchange_finish(v);
-  check(abft_hip_spmv_dot_part_dev(ctx_, mat->handle, v->full, result->handle, off, pair_dev_, ABFT_PART_BOUNDARY),
+  check(abft_hip_spmv_dot_part_dev(ctx_, mat->handle, v->full, result->handle, off, pair_dev_,
+                                   overlap_ ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
         "abft_hip_spmv_dot_part_dev");
   fused_vec_ = vec;
   fused_res_ = result;

@@ -92,6 +92,7 @@ private:
   // all_need_[(src * size + dst) * 2 + {0,1}]: the window [lo, hi) of rank dst's slot that rank src reads
   std::vector<int> all_need_;
   bool use_windows_;             // exchange only those windows (banded matrices) instead of an all-gather
+  bool overlap_;                 // interior rows beside the exchange (long exchanges only)
   abft_hip_vector *pair_;        // two doubles on the device: {partial sum, queued events}
   double *pair_dev_;             // ... their address (asked once: see abft_hip_vector_device_ptr)
   const cg_vector *fused_vec_;   // the last spmv also left vec.result in pair_ (until anything else runs)

@@ -344,7 +344,7 @@ void Comm::allreduce_sum_device(double *dev, int n, void *stream)
   abft_rccl_allreduce_sum(rccl_, dev, n, stream);
 }
 
-void Comm::device_exchange_begin(void *stream) { abft_rccl_exchange_begin(rccl_, stream); }
+void Comm::device_exchange_begin(void *stream, bool beside) { abft_rccl_exchange_begin(rccl_, stream, beside); }
 void Comm::device_exchange_finish(void *stream) { abft_rccl_exchange_finish(rccl_, stream); }
 
 void Comm::allgather_device(double *full, size_t slot)

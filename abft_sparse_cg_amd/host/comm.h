@@ -47,10 +47,12 @@ public:
   bool device_collectives() const { return rccl_ != NULL; }
   // v[0..n) += over ranks, in place, device memory
   void allreduce_sum_device(double *dev, int n, void *stream);
-  // Vector exchange beside compute: between begin and finish the two calls below run on a
-  // side stream that starts after everything enqueued on `stream` so far; finish makes
-  // `stream` wait for them.  Kernels enqueued on `stream` in between overlap the exchange.
-  void device_exchange_begin(void *stream);
+  // Vector exchange: between begin and finish the two calls below run on `stream` itself, or
+  // -- `beside` -- on a side stream that starts after everything enqueued on `stream` so far
+  // and that finish makes `stream` wait for, so kernels enqueued on `stream` in between
+  // overlap the exchange.  The two event hand-offs of that form cost ~20 us per exchange
+  // (measured), so it only pays for exchanges longer than that.
+  void device_exchange_begin(void *stream, bool beside);
   void device_exchange_finish(void *stream);
   // slot `rank` of `full` (size() * slot doubles, device memory) is current; fill the others
   void allgather_device(double *full, size_t slot);
@@ -73,7 +75,7 @@ private:
 void* abft_rccl_init(Comm *host, int device);
 void  abft_rccl_destroy(void *comm);
 void  abft_rccl_allreduce_sum(void *comm, double *dev, int n, void *stream);
-void  abft_rccl_exchange_begin(void *comm, void *stream);
+void  abft_rccl_exchange_begin(void *comm, void *stream, bool beside);
 void  abft_rccl_exchange_finish(void *comm, void *stream);
 void  abft_rccl_allgather(void *comm, double *full, size_t slot, int rank);
 void  abft_rccl_sendrecv(void *comm, const std::vector<Comm::Piece> &out, const std::vector<Comm::Piece> &in);

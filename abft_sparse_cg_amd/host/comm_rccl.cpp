@@ -26,6 +26,8 @@ struct RcclState
   ncclComm_t comm;
   hipStream_t side;
   hipEvent_t ready, done;
+  hipStream_t cur;  // where the exchange in progress is enqueued: `side`, or the caller's stream
+  bool beside;
 };
 
 static void check_hip(hipError_t e, const char *what)
@@ -75,9 +77,13 @@ void abft_rccl_allreduce_sum(void *p, double *dev, int n, void *stream)
   check_nccl(ncclAllReduce(dev, dev, (size_t)n, ncclDouble, ncclSum, st->comm, (hipStream_t)stream), "ncclAllReduce");
 }
 
-void abft_rccl_exchange_begin(void *p, void *stream)
+void abft_rccl_exchange_begin(void *p, void *stream, bool beside)
 {
   RcclState *st = (RcclState *)p;
+  st->beside = beside;
+  st->cur = beside ? st->side : (hipStream_t)stream;
+  if (!beside)
+    return;
   check_hip(hipEventRecord(st->ready, (hipStream_t)stream), "hipEventRecord");
   check_hip(hipStreamWaitEvent(st->side, st->ready, 0), "hipStreamWaitEvent");
 }
@@ -85,6 +91,8 @@ void abft_rccl_exchange_begin(void *p, void *stream)
 void abft_rccl_exchange_finish(void *p, void *stream)
 {
   RcclState *st = (RcclState *)p;
+  if (!st->beside)
+    return;
   check_hip(hipEventRecord(st->done, st->side), "hipEventRecord");
   check_hip(hipStreamWaitEvent((hipStream_t)stream, st->done, 0), "hipStreamWaitEvent");
 }
@@ -93,7 +101,7 @@ void abft_rccl_allgather(void *p, double *full, size_t slot, int rank)
 {
   RcclState *st = (RcclState *)p;
   // in place: this rank's contribution already sits in its slot of the receive buffer
-  check_nccl(ncclAllGather(full + (size_t)rank * slot, full, slot, ncclDouble, st->comm, st->side), "ncclAllGather");
+  check_nccl(ncclAllGather(full + (size_t)rank * slot, full, slot, ncclDouble, st->comm, st->cur), "ncclAllGather");
 }
 
 void abft_rccl_sendrecv(void *p, const std::vector<Comm::Piece> &out, const std::vector<Comm::Piece> &in)
@@ -101,10 +109,10 @@ void abft_rccl_sendrecv(void *p, const std::vector<Comm::Piece> &out, const std:
   RcclState *st = (RcclState *)p;
   check_nccl(ncclGroupStart(), "ncclGroupStart");
   for (size_t k = 0; k < out.size(); k++)
-    check_nccl(ncclSend(out[k].buf, out[k].bytes / sizeof(double), ncclDouble, out[k].peer, st->comm, st->side),
+    check_nccl(ncclSend(out[k].buf, out[k].bytes / sizeof(double), ncclDouble, out[k].peer, st->comm, st->cur),
                "ncclSend");
   for (size_t k = 0; k < in.size(); k++)
-    check_nccl(ncclRecv(in[k].buf, in[k].bytes / sizeof(double), ncclDouble, in[k].peer, st->comm, st->side),
+    check_nccl(ncclRecv(in[k].buf, in[k].bytes / sizeof(double), ncclDouble, in[k].peer, st->comm, st->cur),
                "ncclRecv");
   check_nccl(ncclGroupEnd(), "ncclGroupEnd");
 }
@@ -114,7 +122,7 @@ void abft_rccl_sendrecv(void *p, const std::vector<Comm::Piece> &out, const std:
 void* abft_rccl_init(Comm *, int) { return NULL; }
 void  abft_rccl_destroy(void *) {}
 void  abft_rccl_allreduce_sum(void *, double *, int, void *) { abort(); }
-void  abft_rccl_exchange_begin(void *, void *) { abort(); }
+void  abft_rccl_exchange_begin(void *, void *, bool) { abort(); }
 void  abft_rccl_exchange_finish(void *, void *) { abort(); }
 void  abft_rccl_allgather(void *, double *, size_t, int) { abort(); }
 void  abft_rccl_sendrecv(void *, const std::vector<Comm::Piece> &, const std::vector<Comm::Piece> &) { abort(); }

@@ -230,9 +230,9 @@ def sharded(args):
     if not args.no_profile:
         ms, cnt = eng.ctx.profile_read(capi.K_SPMV)
         if cnt:
-            # a shard with interior rows multiplies in two launches (beside / after the exchange):
+            # a shard that overlaps its exchange multiplies in two launches (beside / after the exchange):
             # the roofline figure is per SpMV, i.e. on the sum of the parts
-            parts = 2 if cg.interior else 1
+            parts = 2 if cg.overlap else 1
             us = ms * 1e3 / cnt * parts
             byts = spmv_bytes("csr", cg.n_loc, counts[rank])
             ach = byts / us / 1e3

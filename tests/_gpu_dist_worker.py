@@ -27,6 +27,7 @@ def main():
     from abft_sparse_cg_amd.distributed import HipEngine, ShardedCG
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = port
+    os.environ.setdefault("ABFT_CG_OVERLAP_BYTES", "0")  # exercise the interior / boundary split at any size
     torch.cuda.set_device(0)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))

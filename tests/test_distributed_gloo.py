@@ -144,6 +144,9 @@ def _worker(rank, world, port, case, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    # interior rows beside the exchange at any exchange size (the product only does so for long
+    # exchanges), unless the case says otherwise: that is the path with the ordering property to check
+    os.environ["ABFT_CG_OVERLAP_BYTES"] = str(case[8]) if len(case) > 8 else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from abft_sparse_cg_amd.distributed import ShardedCG
@@ -283,5 +286,22 @@ def test_fixed_iteration_loop_with_device_scalars(world, matrix):
     assert it_s == iters
     code, it, hist, x, tot, mx, events, _ = run_case(world, (cols, rows, vals, n, bounds, "none", None, iters))
     assert code == 0 and it == iters
+    assert abs(hist[-1] - hist_s[-1]) <= 1e-10 * hist_s[-1]
+    assert np.abs(x - x_s).max() <= 1e-10 * np.abs(x_s).max()
+
+
+@pytest.mark.parametrize("fixed", [0, 9])
+def test_short_exchanges_are_not_overlapped(fixed):
+    """default threshold: the halo of this small banded matrix is exchanged by the blocking
+    collectives and the SpMV runs as one launch -- same iterates"""
+    cols, rows, vals, n = laplace5(24, 24)
+    bounds = uneven_bounds(rows, n, 3)
+    o = OracleMatrix(CSR, "secded", cols, rows, vals, n)
+    if fixed:
+        it_s, hist_s, x_s, _ = o.cg(rhs(n, 1), max_itrs=fixed, conv=0.0)
+    else:
+        it_s, hist_s, x_s, _ = o.cg(rhs(n, 1))
+    code, it, hist, x, tot, mx, events, _ = run_case(3, (cols, rows, vals, n, bounds, "secded", None, fixed, 2 << 20))
+    assert code == 0 and it == it_s and events == []
     assert abs(hist[-1] - hist_s[-1]) <= 1e-10 * hist_s[-1]
     assert np.abs(x - x_s).max() <= 1e-10 * np.abs(x_s).max()

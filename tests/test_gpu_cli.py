@@ -149,6 +149,7 @@ def run_ranks(world, args, opts=()):
     cmd = [os.path.join(HOST, "mgpu-run"), str(world)] + list(opts) + ["--", exe("csr")] + args
     # world 1: still the partitioned code path, with the device collectives on RCCL
     env = dict(os.environ, ABFT_HIP_VERBOSE="1")
+    env.setdefault("ABFT_CG_OVERLAP_BYTES", "0")  # interior rows beside the exchange at any exchange size
     if world == 1:
         env["ABFT_COMM_FORCE"] = "1"
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
@@ -187,7 +188,8 @@ def test_cpp_driver_row_partitioned(world, opts, mode, flip):
     notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
     assert len(notes) == world
     if world > 1:
-        assert all("exchange by windows over TCP" in l and "interior rows [0,0)" not in l for l in notes)
+        assert all("exchange by windows over TCP" in l and "interior rows [0,0)" not in l and
+                   l.endswith("beside the exchange") for l in notes)
     else:
         assert "over RCCL" in notes[0]
 
@@ -222,3 +224,16 @@ def test_run_tests_script_passes_row_partitioned():
     p = subprocess.run([os.path.join(HOST, "run_tests"), launcher], capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, p.stdout
     assert "FAILED" not in p.stdout and p.stdout.count("passed") >= 7 + 1 + 4 * 3 + 1
+
+
+def test_cpp_driver_row_partitioned_short_halo_is_not_overlapped(monkeypatch):
+    """default threshold: this matrix's halo (a few KB) goes in front of a single SpMV launch"""
+    monkeypatch.setenv("ABFT_CG_OVERLAP_BYTES", str(2 << 20))
+    args = ["-f", MTX, "-t", "hip", "-m", "secded", "--flip-at", "1234:70"]
+    one, many = run("csr", args), run_ranks(3, args, ("--one-gpu",))
+    assert one.returncode == 0 and many.returncode == 0, many.stderr[-800:]
+    (rr1, rest1), (rrn, restn) = split_transcript(one.stdout), split_transcript(many.stdout)
+    assert len(rr1) == len(rrn) and all(abs(a - b) <= 1.01e-4 + 1e-10 * a for a, b in zip(rr1, rrn))
+    notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
+    assert len(notes) == 3 and not any(l.endswith("beside the exchange") for l in notes)
+    assert many.stdout.count("[ECC] corrected bit 70 at index 1234\n") == 1
