@@ -17,7 +17,7 @@
 // message on stderr, exit(2).  There is no CPU fallback.
 //
 // Several GPUs: start one process per GPU with RANK / WORLD_SIZE / LOCAL_RANK /
-// MASTER_ADDR / MASTER_PORT set (host/mgpu-run does; so does torch.distributed.run)
+// MASTER_ADDR / MASTER_PORT set (host/mgpu-run does; so does torch.distributed.run --no-python)
 // and every process runs the unchanged driver.  The backend then keeps a row block of
 // the matrix (cut by non-zeros) and the matching slices of every vector on its GPU:
 // spmv is preceded by an all-gather of the input vector, dot and calc_xr end in an
