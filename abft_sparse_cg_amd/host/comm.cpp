@@ -44,7 +44,14 @@ Comm* Comm::from_env()
     exit(2);
   }
   const char *addr = getenv("MASTER_ADDR");
-  c->connect_star(addr && *addr ? addr : "127.0.0.1", env_int("MASTER_PORT", 29400));
+  // ABFT_COMM_PORT if given; else MASTER_PORT -- plus one under torch.distributed.run, whose agent
+  // keeps its own store listening on MASTER_PORT itself
+  int port = env_int("MASTER_PORT", 29400);
+  const char *agent = getenv("TORCHELASTIC_USE_AGENT_STORE");
+  if (agent && !strcmp(agent, "True"))
+    port += 1;
+  port = env_int("ABFT_COMM_PORT", port);
+  c->connect_star(addr && *addr ? addr : "127.0.0.1", port);
   return c;
 }
 

@@ -237,3 +237,17 @@ def test_cpp_driver_row_partitioned_short_halo_is_not_overlapped(monkeypatch):
     notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
     assert len(notes) == 3 and not any(l.endswith("beside the exchange") for l in notes)
     assert many.stdout.count("[ECC] corrected bit 70 at index 1234\n") == 1
+
+
+def test_cpp_driver_row_partitioned_under_torchrun():
+    """the launcher the driver of this repository uses for bench.py also starts the C++ executable
+    (--no-python): its agent keeps MASTER_PORT for itself, our rendezvous moves one port up"""
+    env = dict(os.environ, ABFT_COMM="tcp", ABFT_HIP_DEVICE="0", ABFT_HIP_VERBOSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--no-python", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29613", exe("csr"), "-t", "hip", "-m", "secded", "-f", MTX]
+    many = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    one = run("csr", ["-t", "hip", "-m", "secded", "-f", MTX])
+    assert many.returncode == 0 and one.returncode == 0, many.stderr[-1500:]
+    (rr1, rest1), (rrn, restn) = split_transcript(one.stdout), split_transcript(many.stdout)
+    assert len(rr1) == len(rrn) and all(abs(a - b) <= 1.01e-4 + 1e-10 * a for a, b in zip(rr1, rrn))
+    assert sum(l.startswith("hip backend: rank") for l in many.stderr.splitlines()) == 2
