@@ -251,3 +251,10 @@ def test_cpp_driver_row_partitioned_under_torchrun():
     (rr1, rest1), (rrn, restn) = split_transcript(one.stdout), split_transcript(many.stdout)
     assert len(rr1) == len(rrn) and all(abs(a - b) <= 1.01e-4 + 1e-10 * a for a, b in zip(rr1, rrn))
     assert sum(l.startswith("hip backend: rank") for l in many.stderr.splitlines()) == 2
+
+
+def test_cpp_coo_driver_refuses_several_ranks_loudly():
+    cmd = [os.path.join(HOST, "mgpu-run"), "2", "--one-gpu", "--", exe("coo"), "-t", "hip", "-m", "none", "-f", MTX]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2
+    assert "shards CSR" in p.stderr and "ran for" not in p.stdout
