@@ -54,6 +54,7 @@ struct abft_hip_ctx {
   HostSlot *host_slot = nullptr;      // pinned, device-visible
   HostSlot *host_slot_dev = nullptr;  // its device alias
   EventRing ring{};                   // device memory
+  MovedList moved{};                  // COO elements with a silently corrupted column (device memory)
   int *bits_dev = nullptr;            // scratch for inject (32 ints)
   // cross-call fusion: the last spmv also produced vec.result (see FuseOut)
   bool fuse_enabled = true;
@@ -109,6 +110,7 @@ struct abft_hip_vector {
 };
 
 static constexpr uint32_t EVENT_CAP = 1u << 16;
+static constexpr uint32_t MOVED_CAP = 4096;
 
 static int flush_deferred(abft_hip_ctx *ctx) {
   if (!ctx->defer.active) return ABFT_OK;
@@ -222,6 +224,10 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   HIPCHK(hipMalloc((void **)&ctx->ring.count, sizeof(uint32_t)));
   HIPCHK(hipMemset(ctx->ring.count, 0, sizeof(uint32_t)));
   ctx->ring.cap = EVENT_CAP;
+  HIPCHK(hipMalloc((void **)&ctx->moved.buf, 2 * (size_t)MOVED_CAP * sizeof(MovedEntry)));
+  HIPCHK(hipMalloc((void **)&ctx->moved.count, sizeof(uint32_t)));
+  HIPCHK(hipMemset(ctx->moved.count, 0, sizeof(uint32_t)));
+  ctx->moved.cap = MOVED_CAP;
   HIPCHK(hipMalloc((void **)&ctx->bits_dev, 32 * sizeof(int)));
   // Load the code object and run each vector kernel once here, not inside the
   // caller's timed loop (the reference driver starts its clock right before the
@@ -255,6 +261,8 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
   (void)hipFree(ctx->ring.count);
+  (void)hipFree(ctx->moved.buf);
+  (void)hipFree(ctx->moved.count);
   (void)hipFree(ctx->bits_dev);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -532,6 +540,7 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   CooDev &A = m->coo;
   A.n_out = (uint32_t)n_out; A.n_in = (uint32_t)n_in; A.nnz = (uint32_t)nnz; A.index_base = index_base;
   A.nblk = (uint32_t)blk.size();
+  A.moved = ctx->moved;
   int rc;
   uint32_t *d_grp = nullptr, *d_orig = nullptr, *d_pos = nullptr;
   uint4 *d_el = nullptr, *d_blk = nullptr;
@@ -1026,6 +1035,10 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
                              ctx->stream));
     else
       HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
+    // products whose stored column was silently corrupted go where the reference puts them
+    if (mat->fmt == ABFT_FMT_COO)
+      HIPCHK(launch_coo_fixup(mat->mode, mat->coo, mat->use_panels ? &mat->panels : nullptr, vec->d, result->d,
+                              ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
   }
   if (part == ABFT_PART_INTERIOR) return ABFT_OK;  // the boundary call folds and publishes
   if (do_fuse) {
@@ -1095,6 +1108,8 @@ extern "C" int abft_format_event(const abft_event *ev, char *buf, size_t cap) {
     case ABFT_EV_COL_ORDER:
       return snprintf(buf, cap, coo ? "column index order violated at index %d\n"
                                     : "column order constraint violated at index %d\n", i);
+    case ABFT_EV_MOVED_OVERFLOW:
+      return snprintf(buf, cap, "hip: more than %d COO elements carry a silently corrupted column\n", i);
     default: return snprintf(buf, cap, "unknown event %u\n", ev->kind);
   }
 }

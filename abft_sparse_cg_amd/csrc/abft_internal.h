@@ -48,6 +48,23 @@ struct CsrPanels {
 constexpr int ABFT_PANEL_ROWS_PER_THREAD = ABFT_CFG_PANEL_RPT;
 constexpr int ABFT_PANEL_ROWS = 256 * ABFT_PANEL_ROWS_PER_THREAD;
 
+// COO only: elements whose stored column no longer names the output group they are
+// stored in (a silently corrupted column: modes none/constraints, or multi-bit damage
+// an ECC mode cannot see).  The reference scatters such a product into
+// result[corrupted col] (COO/CPUContext.cpp:120); the SpMV kernels leave it out of the
+// group's sum and queue it here, and coo_fixup_kernel, launched behind every COO SpMV,
+// rebuilds each receiving output in the caller's element order.  Empty on clean data.
+struct MovedEntry {
+  uint32_t orig;  // caller's (local) element index: the position in the reference's serial loop
+  uint32_t col;   // the output the reference adds this product to (< n_out)
+  double prod;    // value * vec[row], as the SpMV formed it
+};
+struct MovedList {
+  MovedEntry *buf;     // 2 * cap entries: [0, cap) filled by the SpMV, [cap, 2 cap) sorted by the fix-up
+  uint32_t *count;     // entries pushed by the SpMV in flight (reset by the fix-up)
+  uint32_t cap;
+};
+
 // COO matrix: 16-byte elements {col,row,value} (COO/ecc.h:11-16) stored grouped
 // by output index (col) and, inside a group, in the caller's order -- so each
 // output is still summed in the reference's storage order.
@@ -58,6 +75,7 @@ struct CooDev {
   const uint32_t *orig_index;   // stored position -> caller's element index (cold path)
   const uint32_t *pos_of_orig;  // caller's element index -> stored position
   uint32_t nblk, n_out, n_in, nnz, index_base;
+  MovedList moved;
 };
 
 #define ABFT_COLMASK_HOST 0x00FFFFFFu
@@ -167,6 +185,9 @@ hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, cons
                            const FuseOut *fuse, hipStream_t s);
 hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);
+// behind every COO SpMV (and before the fold of a fused product): see MovedList
+hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y,
+                            EventRing ev, const FuseOut *fuse, hipStream_t s);
 
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);

@@ -646,10 +646,14 @@ hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, cons
 // instruction), ECC over the 4 words, gather x[row], park value*x in LDS.
 // Constraints mode (reference COO/CPUContext.cpp:155-188) compares with the
 // caller-order successor, reached through the two permutation arrays.
+// Also parks the element's column -- masked in the ECC modes, after any repair: the
+// output the reference adds the product to (COO/CPUContext.cpp:120, :224, :267, :320,
+// :376) -- so that the summing phase can tell an element whose column no longer names
+// the group it is stored in (see MovedList).
 template <int MODE, int EPT>
 __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restrict__ x,
                                           const EventRing &ev, uint32_t lo, uint32_t hi,
-                                          double *s_prod) {
+                                          double *s_prod, uint32_t *s_col) {
   u32x4 e[EPT];
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
@@ -690,6 +694,7 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
     row[s] = w[1];
     val[s] = as_double(w[2], w[3]);
     ok[s] = valid;
+    s_col[threadIdx.x + (uint32_t)s * ABFT_BLOCK] = MODE >= MODE_SED ? (w[0] & ABFT_COLMASK) : w[0];
   }
   double xv[EPT];
 #pragma unroll
@@ -705,19 +710,53 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
   }
 }
 
-// ordered sum of LDS slots [a, b): four reads in flight, adds in slot order
-__device__ __forceinline__ double lds_ordered_sum(const double *s_prod, uint32_t a, uint32_t b) {
-  double acc = 0.0;
+// Cold: the product staged at LDS slot k (stored position j) belongs to output `col`,
+// not to the group it is stored in.  Queue it for coo_fixup_kernel; a column outside
+// the result vector is dropped (the reference writes out of bounds there: undefined).
+// (everything by value, in registers: a reference to the kernel's CooDev would put the
+// whole argument struct into scratch memory and the hot path would read it from there)
+__device__ __noinline__ void coo_push_moved_cold(MovedEntry *buf, uint32_t *count, uint32_t cap,
+                                                 const uint32_t *orig_index, abft_event *evbuf, uint32_t *evcount,
+                                                 uint32_t evcap, uint32_t j, uint32_t col, double prod) {
+  const uint32_t slot = atomicAdd(count, 1u);
+  if (slot < cap) {
+    MovedEntry m;
+    m.orig = orig_index[j]; m.col = col; m.prod = prod;
+    buf[slot] = m;
+  } else if (slot == cap) {
+    EventRing ev;
+    ev.buf = evbuf; ev.count = evcount; ev.cap = evcap;
+    push_event(ev, ABFT_EV_MOVED_OVERFLOW, cap, 0, FMT_COO);
+  }
+}
+__device__ __forceinline__ void coo_push_moved(const CooDev &A, const EventRing &ev, uint32_t j, uint32_t col,
+                                               double prod) {
+  if (col < A.n_out)
+    coo_push_moved_cold(A.moved.buf, A.moved.count, A.moved.cap, A.orig_index, ev.buf, ev.count, ev.cap, j, col, prod);
+}
+
+// Continue the ordered sum of output `out` over LDS slots [a, b) from `acc`: four reads
+// in flight, adds in slot order.  A slot whose staged column is not `out` is left out of
+// the sum (no "+ 0.0") and queued for the fix-up; `j0` = stored position of slot 0.
+__device__ __forceinline__ void lds_ordered_add(const CooDev &A, const EventRing &ev, const double *s_prod,
+                                                const uint32_t *s_col, uint32_t a, uint32_t b, uint32_t out,
+                                                uint32_t j0, double &acc) {
   for (uint32_t k = a; k < b; k += 4u) {
     const uint32_t last = b - 1u;
-    const double a0 = s_prod[k], a1 = s_prod[min(k + 1u, last)], a2 = s_prod[min(k + 2u, last)],
-                 a3 = s_prod[min(k + 3u, last)];
-    acc += a0;
-    if (k + 1u < b) acc += a1;
-    if (k + 2u < b) acc += a2;
-    if (k + 3u < b) acc += a3;
+    const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
+    const double a0 = s_prod[k], a1 = s_prod[k1], a2 = s_prod[k2], a3 = s_prod[k3];
+    const uint32_t c0 = s_col[k], c1 = s_col[k1], c2 = s_col[k2], c3 = s_col[k3];
+    if (c0 == out) acc += a0;
+    if (k + 1u < b && c1 == out) acc += a1;
+    if (k + 2u < b && c2 == out) acc += a2;
+    if (k + 3u < b && c3 == out) acc += a3;
+    if (__builtin_expect(((c0 ^ out) | (c1 ^ out) | (c2 ^ out) | (c3 ^ out)) != 0u, 0)) {
+      if (c0 != out) coo_push_moved(A, ev, j0 + k, c0, a0);
+      if (k + 1u < b && c1 != out) coo_push_moved(A, ev, j0 + k + 1u, c1, a1);
+      if (k + 2u < b && c2 != out) coo_push_moved(A, ev, j0 + k + 2u, c2, a2);
+      if (k + 3u < b && c3 != out) coo_push_moved(A, ev, j0 + k + 3u, c3, a3);
+    }
   }
-  return acc;
 }
 
 // COO SpMV, all modes: result[col] += value * vec[row] (reference
@@ -731,6 +770,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
                                                               FuseOut fuse) {
   constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[TILE];
   const uint32_t t = xcd_tile(blockIdx.x, A.nblk);
   const uint4 desc = A.blk[t];
   const uint32_t g0 = desc.x, g1 = desc.y, e0 = desc.z, e1 = desc.w;
@@ -744,7 +784,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
       gs = A.grp_ptr[g]; ge = A.grp_ptr[g + 1];  // (the uniform-block shortcut of the CSR kernel measured 4 % slower here)
       if (FUSE) xg = x[fuse.x_off + g];
     }
-    coo_stage<MODE, EPT>(A, x, ev, e0, e1, s_prod);
+    coo_stage<MODE, EPT>(A, x, ev, e0, e1, s_prod, s_col);
     __syncthreads();
     for (uint32_t grp = g; grp < g1; grp += ABFT_BLOCK) {
       if (grp != g) {
@@ -752,7 +792,8 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
         if (FUSE) xg = x[fuse.x_off + grp];
       }
       // reference zero-fills result first (COO/CPUContext.cpp:108-109)
-      const double acc = lds_ordered_sum(s_prod, gs - e0, ge - e0);
+      double acc = 0.0;
+      lds_ordered_add(A, ev, s_prod, s_col, gs - e0, ge - e0, grp, e0, acc);
       y[grp] = acc;
       if (FUSE) dsum += xg * acc;
     }
@@ -763,10 +804,9 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
       for (uint32_t lo = gs; lo < ge;) {
         const uint32_t hi = min(ge, lo + TILE);
         __syncthreads();
-        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod);
+        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod, s_col);
         __syncthreads();
-        if (threadIdx.x == 0)
-          for (uint32_t j = lo; j < hi; j++) acc += s_prod[j - lo];
+        if (threadIdx.x == 0) lds_ordered_add(A, ev, s_prod, s_col, 0u, hi - lo, grp, lo, acc);
         lo = hi;
       }
       if (threadIdx.x == 0) {
@@ -776,19 +816,6 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
     }
   }
   if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
-}
-
-// continue an ordered sum over LDS slots [a, b) from `acc` (see lds_ordered_sum)
-__device__ __forceinline__ void lds_ordered_add(const double *s_prod, uint32_t a, uint32_t b, double &acc) {
-  for (uint32_t k = a; k < b; k += 4u) {
-    const uint32_t last = b - 1u;
-    const double a0 = s_prod[k], a1 = s_prod[min(k + 1u, last)], a2 = s_prod[min(k + 2u, last)],
-                 a3 = s_prod[min(k + 3u, last)];
-    acc += a0;
-    if (k + 1u < b) acc += a1;
-    if (k + 2u < b) acc += a2;
-    if (k + 3u < b) acc += a3;
-  }
 }
 
 // Panel-layout COO SpMV: the CSR panel kernel with (output group, row panel)
@@ -802,6 +829,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
   constexpr uint32_t TILE = ABFT_BLOCK * EPT;
   constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[TILE];
   double dsum = 0.0;
   for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x) {
     const uint32_t out0 = g * ABFT_PANEL_ROWS;
@@ -826,14 +854,15 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
       for (uint32_t lo = e0; lo < e1;) {
         const uint32_t hi = min(e1, lo + TILE);
         __syncthreads();
-        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod);
+        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod, s_col);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
           const uint32_t a0 = max(gs[j], lo), a1 = min(ge[j], hi);
           if (a0 < a1) {
             double t = acc[j];
-            lds_ordered_add(s_prod, a0 - lo, a1 - lo, t);
+            lds_ordered_add(A, ev, s_prod, s_col, a0 - lo, a1 - lo, out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x,
+                            lo, t);
             acc[j] = t;
           }
         }
@@ -911,6 +940,110 @@ hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y
     case MODE_SECDED: return launch_spmv_coo_mode<MODE_SECDED>(A, x, y, ev, fuse, s);
     default: return hipErrorInvalidValue;
   }
+}
+
+// ------------------------------------------------- COO: corrupted-column fix-up --
+
+// Launched behind every COO SpMV (one workgroup; returns at once when the SpMV queued
+// nothing, which is every launch on clean data).  The SpMV left each moved product out of
+// the sum of the group it is stored in -- that output is already what the reference
+// computes -- and queued {caller's index, new column, product}.  Here every output that
+// RECEIVES products is rebuilt from 0.0 as the reference's serial loop builds it
+// (COO/CPUContext.cpp:111-120): its own elements that still name it, re-multiplied from
+// the (repaired) stored words, merged by caller's index with the queued products.
+// Stored order inside a group is the caller's order in both layouts, so the merge is a
+// two-way merge.  A fused vec.result product is corrected through partial 0.
+template <int MODE>
+__global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, CsrPanels P, bool panels,
+                                                               const double *__restrict__ x, double *__restrict__ y,
+                                                               FuseOut fuse, bool fused) {
+  __shared__ double s_p[ABFT_BLOCK];
+  __shared__ uint32_t s_o[ABFT_BLOCK];
+  __shared__ uint32_t s_n[ABFT_BLOCK];
+  uint32_t n = __hip_atomic_load(A.moved.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (n == 0u) return;  // uniform
+  if (n > A.moved.cap) n = A.moved.cap;
+  const MovedEntry *in = A.moved.buf;
+  MovedEntry *srt = A.moved.buf + A.moved.cap;
+  // rank sort by (column, caller's index); keys are distinct
+  for (uint32_t i = threadIdx.x; i < n; i += ABFT_BLOCK) {
+    const MovedEntry e = in[i];
+    uint32_t rank = 0;
+    for (uint32_t k = 0; k < n; k++) {
+      const MovedEntry o = in[k];
+      rank += (o.col < e.col || (o.col == e.col && o.orig < e.orig)) ? 1u : 0u;
+    }
+    srt[rank] = e;
+  }
+  __threadfence();
+  __syncthreads();
+  uint32_t q = 0;  // uniform cursor over the sorted entries
+  while (q < n) {
+    const uint32_t c = srt[q].col;
+    uint32_t q1 = q;
+    while (q1 < n && srt[q1].col == c) q1++;
+    double sum = 0.0;   // thread 0 only
+    uint32_t qi = q;    // thread 0 only
+    const uint32_t nranges = panels ? P.npanels : 1u;
+    for (uint32_t rg = 0; rg < nranges; rg++) {
+      uint32_t lo, hi;
+      if (panels) {
+        const uint32_t seg = (c / ABFT_PANEL_ROWS) * P.npanels + rg;
+        const uint32_t e0 = P.seg_base[seg];
+        const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+        lo = e0 + ptr[c % ABFT_PANEL_ROWS];
+        hi = e0 + ptr[c % ABFT_PANEL_ROWS + 1];
+      } else {
+        lo = A.grp_ptr[c]; hi = A.grp_ptr[c + 1];
+      }
+      for (uint32_t base = lo; base < hi; base += ABFT_BLOCK) {
+        const uint32_t j = base + threadIdx.x;
+        if (j < hi) {
+          const uint4 e = A.elems[j];
+          const uint32_t col = MODE >= MODE_SED ? (e.x & ABFT_COLMASK) : e.x;
+          const bool in_range = e.y < A.n_in;
+          const double xv = in_range ? x[e.y] : 0.0;
+          s_p[threadIdx.x] = as_double(e.z, e.w) * xv;
+          s_o[threadIdx.x] = A.orig_index[j];
+          s_n[threadIdx.x] = col == c ? 1u : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          const uint32_t cnt = min((uint32_t)ABFT_BLOCK, hi - base);
+          for (uint32_t k = 0; k < cnt; k++) {
+            if (!s_n[k]) continue;  // moved out itself
+            while (qi < q1 && srt[qi].orig < s_o[k]) sum += srt[qi++].prod;
+            sum += s_p[k];
+          }
+        }
+        __syncthreads();
+      }
+    }
+    if (threadIdx.x == 0) {
+      while (qi < q1) sum += srt[qi++].prod;
+      const double old = y[c];
+      y[c] = sum;
+      if (fused) {
+        const double xo = x[fuse.x_off + c];
+        fuse.partials[0] += xo * sum - xo * old;
+      }
+    }
+    q = q1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(A.moved.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y,
+                            EventRing ev, const FuseOut *fuse, hipStream_t s) {
+  (void)ev;
+  if (!A.moved.buf || A.nnz == 0) return hipSuccess;
+  const CsrPanels pp = P ? *P : CsrPanels{};
+  const FuseOut f = fuse ? *fuse : FuseOut{};
+#define ABFT_FIX(M) hipLaunchKernelGGL(coo_fixup_kernel<M>, dim3(1), dim3(ABFT_BLOCK), 0, s, A, pp, P != nullptr, x, y, f, fuse != nullptr)
+  if (mode >= MODE_SED) ABFT_FIX(MODE_SED); else ABFT_FIX(MODE_NONE);
+#undef ABFT_FIX
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------ fault injection --

@@ -63,7 +63,11 @@ typedef enum {
   ABFT_EV_ROW_SIZE = 5,         /* "row size constraint violated for ..."           fatal */
   ABFT_EV_ROW_ORDER = 6,        /* "row order constraint violated ..."              fatal */
   ABFT_EV_COL_SIZE = 7,         /* "column size constraint violated ..."            fatal */
-  ABFT_EV_COL_ORDER = 8         /* "column order constraint violated ..."           fatal */
+  ABFT_EV_COL_ORDER = 8,        /* "column order constraint violated ..."           fatal */
+  /* not a reference line: more COO elements carry a silently corrupted column than the
+   * engine's list holds (index = its capacity); results past this point are not the
+   * reference's, so the event is fatal */
+  ABFT_EV_MOVED_OVERFLOW = 9
 } abft_event_kind;
 
 typedef struct {
