@@ -79,6 +79,7 @@ SIGNATURES = {
     "abft_hip_calc_xr_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "abft_hip_calc_p_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp]),
     "abft_hip_drain_events": (C.c_int, [vp, C.POINTER(Event), C.c_int, i32p, i32p]),
+    "abft_hip_event_capacity": (C.c_int, []),
     "abft_hip_pending_events": (C.c_int, [vp]),
     "abft_format_event": (C.c_int, [C.POINTER(Event), C.c_char_p, C.c_size_t]),
     "abft_event_is_fatal": (C.c_int, [C.c_uint32]),

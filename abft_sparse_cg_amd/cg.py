@@ -60,7 +60,7 @@ def fail(msg):
 
 
 def parse(argv):
-    o = dict(num_blocks=25, max_itrs=1000, conv=0.001, matrix_file=DEFAULT_MTX, synthetic=None, target="hip",
+    o = dict(num_blocks=25, max_itrs=1000, conv=0.001, matrix_file=DEFAULT_MTX, synthetic=None, target="cpu",
              mode="none", flips=0, kind="ANY", seed=None, quiet=False, flip_at=None, fmt="csr", list=False)
 
     def num(s, conv):

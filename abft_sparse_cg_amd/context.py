@@ -67,6 +67,7 @@ class HIPContext:
         check(self.L.abft_hip_init(device, C.byref(h)))
         self.h = h
         self.event_log = []
+        self._evbuf, self._evcap = None, 0
         self.prof_mask = 0
         self._live = []  # matrices and vectors not yet destroyed, in creation order
 
@@ -232,10 +233,12 @@ class HIPContext:
 
     def drain_events(self):
         """-> ([(kind, index, bit)], fatal) -- raw, nothing printed."""
-        buf = (capi.Event * 4096)()
+        if self._evbuf is None:  # sized to the device queue: drain never truncates
+            self._evcap = self.L.abft_hip_event_capacity()
+            self._evbuf = (capi.Event * self._evcap)()
         n, fatal = C.c_int(0), C.c_int(0)
-        check(self.L.abft_hip_drain_events(self.h, buf, 4096, C.byref(n), C.byref(fatal)))
-        return [buf[i].tup() for i in range(n.value)], bool(fatal.value)
+        check(self.L.abft_hip_drain_events(self.h, self._evbuf, self._evcap, C.byref(n), C.byref(fatal)))
+        return [self._evbuf[i].tup() for i in range(n.value)], bool(fatal.value)
 
     def _drain_if_pending(self):
         if self.L.abft_hip_pending_events(self.h):

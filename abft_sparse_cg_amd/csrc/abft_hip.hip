@@ -1125,7 +1125,8 @@ extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap
   HIPCHK(hipMemcpyAsync(&n, ctx->ring.count, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (n == 0) { ctx->host_slot->evcount = 0; return ABFT_OK; }
-  if (n > ctx->ring.cap) n = ctx->ring.cap;
+  const uint32_t queued = n;
+  if (n > ctx->ring.cap) n = ctx->ring.cap;  // push_event dropped the rest: reported below, never silently
   std::vector<abft_event> ev(n);
   HIPCHK(hipMemcpyAsync(ev.data(), ctx->ring.buf, (size_t)n * sizeof(abft_event), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->ring.count, 0, sizeof(uint32_t), ctx->stream));
@@ -1134,14 +1135,26 @@ extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap
   std::sort(ev.begin(), ev.end(), [](const abft_event &a, const abft_event &b) {
     return a.index != b.index ? a.index < b.index : a.kind < b.kind;
   });
-  int out = 0;
-  for (uint32_t i = 0; i < n && out < cap; i++) {
-    buf[out++] = ev[i];
-    if (abft_event_is_fatal(ev[i].kind)) { if (fatal) *fatal = 1; break; }
+  // the reference stops at its first fatal line: look at ALL queued events for it, then
+  // hand over what precedes it (a short caller buffer must not hide a fatal event)
+  uint32_t want = n;
+  for (uint32_t i = 0; i < n; i++)
+    if (abft_event_is_fatal(ev[i].kind)) { want = i + 1; if (fatal) *fatal = 1; break; }
+  const uint32_t out = std::min<uint32_t>(want, (uint32_t)cap);
+  for (uint32_t i = 0; i < out; i++) buf[i] = ev[i];
+  *count = (int)out;
+  if (queued > ctx->ring.cap) {
+    if (fatal) *fatal = 1;
+    return set_err(ABFT_ERR_RANGE, "event ring overflow: %u events queued, %u kept -- the lines past this point "
+                   "are not the reference's", queued, ctx->ring.cap);
   }
-  *count = out;
+  if (out < want)
+    return set_err(ABFT_ERR_RANGE, "drain buffer of %d events is too small for the %u due (ring capacity %u)", cap,
+                   want, ctx->ring.cap);
   return ABFT_OK;
 }
+
+extern "C" int abft_hip_event_capacity(void) { return (int)EVENT_CAP; }
 
 // -------------------------------------------------------------- measurement --
 

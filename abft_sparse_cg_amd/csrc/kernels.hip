@@ -332,7 +332,6 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
   for (int j = 0; j < EPT; j++) {
     const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
     xv[j] = gather_load(x + (in ? col[j] : 0u));
-    ok[j] = in ? ok[j] : ok[j];
     if (!in) xv[j] = 0.0;
   }
   // no branch around the prefetch: with one, hipcc drains the whole memory queue

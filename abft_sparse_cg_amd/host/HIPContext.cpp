@@ -74,9 +74,14 @@ void HIPContextBase::report_events(bool force)
 {
   if (!comm_ && !force && abft_hip_pending_events(ctx_) == 0)
     return;
-  static abft_event events[4096];
+  // sized to the device queue: nothing is cut off here (a run that overflows the queue
+  // itself ends below with the library's message, after printing what was kept)
+  static std::vector<abft_event> buffer((size_t)abft_hip_event_capacity());
+  abft_event *events = buffer.data();
   int count = 0, fatal = 0;
-  check(abft_hip_drain_events(ctx_, events, 4096, &count, &fatal), "abft_hip_drain_events");
+  const int drain_rc = abft_hip_drain_events(ctx_, events, (int)buffer.size(), &count, &fatal);
+  if (drain_rc != ABFT_OK && drain_rc != ABFT_ERR_RANGE)
+    check(drain_rc, "abft_hip_drain_events");
   std::vector<abft_event> all(events, events + count);
   if (comm_)
   {
@@ -101,6 +106,8 @@ void HIPContextBase::report_events(bool force)
     abft_format_event(&all[i], line, sizeof(line));
     fputs(line, stdout);
   }
+  if (drain_rc == ABFT_ERR_RANGE)
+    check(drain_rc, "abft_hip_drain_events");
   if (fatal)
   {
     fflush(stdout);

@@ -4,6 +4,7 @@
 #include <arpa/inet.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
+#include <poll.h>
 #include <sys/socket.h>
 #include <sys/time.h>
 #include <unistd.h>
@@ -88,17 +89,43 @@ void Comm::connect_star(const char *addr, int port)
     memset(&sa, 0, sizeof(sa));
     sa.sin_family = AF_INET;
     sa.sin_port = htons((uint16_t)port);
+    // one node: listen on the loopback address when that is what the ranks were given
+    in_addr local;
     sa.sin_addr.s_addr = htonl(INADDR_ANY);
+    if (inet_pton(AF_INET, addr, &local) == 1 && (ntohl(local.s_addr) >> 24) == 127)
+      sa.sin_addr = local;
     if (bind(listen_fd_, (sockaddr *)&sa, sizeof(sa)) < 0) die("bind (MASTER_PORT in use?)");
     if (listen(listen_fd_, size_) < 0) die("listen");
     peers_.assign(size_, -1);
+    // a peer that died before connecting (bad device, failed exec) must not leave rank 0
+    // -- and the launcher waiting on it -- blocked for ever: one deadline for the rendezvous
+    const int limit_s = env_int("ABFT_COMM_TIMEOUT", 120);
+    timeval t0;
+    gettimeofday(&t0, NULL);
     for (int k = 1; k < size_; k++)
     {
+      timeval now;
+      gettimeofday(&now, NULL);
+      const long left_ms = (long)limit_s * 1000 - ((now.tv_sec - t0.tv_sec) * 1000 + (now.tv_usec - t0.tv_usec) / 1000);
+      pollfd pf = {listen_fd_, POLLIN, 0};
+      if (left_ms <= 0 || poll(&pf, 1, (int)left_ms) <= 0)
+      {
+        fflush(stdout);
+        fprintf(stderr, "hip backend (comm): rendezvous timed out after %d s; missing rank(s):", limit_s);
+        for (int r = 1; r < size_; r++)
+          if (peers_[r] < 0) fprintf(stderr, " %d", r);
+        fprintf(stderr, "\n");
+        exit(2);
+      }
       int fd = accept(listen_fd_, NULL, NULL);
       if (fd < 0) die("accept");
       setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+      timeval hello_to = {10, 0};  // the hello follows the connect at once
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hello_to, sizeof(hello_to));
       int hello[2] = {0, -1};  // {magic, rank}
       recv_all(fd, hello, sizeof(hello));
+      timeval none = {0, 0};
+      setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &none, sizeof(none));
       const int who = hello[1];
       if (hello[0] != kMagic || who <= 0 || who >= size_ || peers_[who] >= 0)
       {

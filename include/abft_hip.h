@@ -238,6 +238,10 @@ int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const ab
  * single-threaded reference run prints them in.  *count = events returned,
  * *fatal = 1 if the last one is fatal (the reference would have exit(1)ed). */
 int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap, int *count, int *fatal);
+/* Capacity of the device event queue = the `cap` with which drain never truncates.
+ * drain returns ABFT_ERR_RANGE (after filling buf / count / fatal) if the device queued
+ * more events than that, or if `cap` is smaller than the events due. */
+int abft_hip_event_capacity(void);
 /* Number of events queued as of the last synchronising call (no sync). */
 int abft_hip_pending_events(abft_hip_ctx *ctx);
 /* The reference's exact printf line for an event, including the newline. */

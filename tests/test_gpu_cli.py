@@ -28,8 +28,13 @@ def exe(fmt):
     return p
 
 
-def run(fmt, args):
-    return subprocess.run([exe(fmt)] + args, capture_output=True, text=True, timeout=300)
+def run(fmt, args, env=None):
+    # the driver's default target is the reference's, "cpu" (cg.cpp:191); these executables
+    # register hip-* only, so every run names it
+    if "-t" not in args and "--list" not in args and "--bogus" not in args:
+        args = ["-t", "hip"] + args
+    return subprocess.run([exe(fmt)] + args, capture_output=True, text=True, timeout=300,
+                          env=dict(os.environ, **(env or {})))
 
 
 def numbers_close(a, b, tol):
@@ -94,6 +99,8 @@ def test_sed_detects_and_exits_1():
 
 def test_cli_errors_like_reference():
     assert run("csr", ["-t", "cpu"]).returncode == 1  # not registered in this executable
+    out = subprocess.run([exe("csr"), "-f", MTX], capture_output=True, text=True, timeout=60)  # default target = cpu
+    assert out.returncode == 1 and "No implementation found for cpu-none" in out.stderr
     out = run("csr", ["-f", "/nonexistent.mtx"])
     assert out.returncode == 1 and out.stdout == "Failed to open '/nonexistent.mtx'\n"
     out = run("csr", ["--bogus"])
@@ -114,6 +121,8 @@ def test_synthetic_input_and_fixed_iterations():
 
 def run_py(args, sharded=False):
     env = dict(os.environ, PYTHONPATH=ROOT)
+    if "-t" not in args:
+        args = ["-t", "hip"] + args
     if sharded:
         env["ABFT_CG_SHARDED"] = "1"
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
@@ -145,10 +154,18 @@ def test_python_driver_transcripts_match_reference(sharded):
 # ---- row-partitioned by the backend.  On a one-GPU box the ranks share GPU 0 and the
 # ---- collectives are staged through the host (--one-gpu); RCCL runs at world size 1.
 
-def run_ranks(world, args, opts=()):
-    cmd = [os.path.join(HOST, "mgpu-run"), str(world)] + list(opts) + ["--", exe("csr")] + args
+def hex_history(stderr):
+    """ABFT_CG_HEX=1: 'rr <iteration> <%a>' lines on stderr -> {iteration: [value per rank that printed]}"""
+    hist = {}
+    for m in re.finditer(r"^rr (\d+) (\S+)$", stderr, re.M):
+        hist.setdefault(int(m.group(1)), []).append(float.fromhex(m.group(2)))
+    return hist
+
+
+def run_ranks(world, args, opts=(), fmt="csr"):
+    cmd = [os.path.join(HOST, "mgpu-run"), str(world)] + list(opts) + ["--", exe(fmt)] + args
     # world 1: still the partitioned code path, with the device collectives on RCCL
-    env = dict(os.environ, ABFT_HIP_VERBOSE="1")
+    env = dict(os.environ, ABFT_HIP_VERBOSE="1", ABFT_CG_HEX="1")
     env.setdefault("ABFT_CG_OVERLAP_BYTES", "0")  # interior rows beside the exchange at any exchange size
     if world == 1:
         env["ABFT_COMM_FORCE"] = "1"
@@ -171,13 +188,19 @@ def test_cpp_driver_row_partitioned(world, opts, mode, flip):
     """same report, same iteration count, rr lines within the reductions' tolerance, the ECC line
     once and with its global index -- against the one-process run of the same executable"""
     args = ["-f", MTX, "-t", "hip", "-m", mode] + (["--flip-at", flip] if flip else [])
-    one = run("csr", args)
+    one = run("csr", args, env={"ABFT_CG_HEX": "1"})
     many = run_ranks(world, args, opts)
     assert one.returncode == 0 and many.returncode == 0, many.stdout[-400:] + many.stderr[-800:]
     rr1, rest1 = split_transcript(one.stdout)
     rrn, restn = split_transcript(many.stdout)
     assert len(rr1) == len(rrn) > 50
     assert all(abs(a - b) <= 1.01e-4 + 1e-10 * a for a, b in zip(rr1, rrn))
+    # the residual history with all its bits (north_star: within 1e-10 relative), every rank's copy
+    h1, hn = hex_history(one.stderr), hex_history(many.stderr)
+    assert sorted(h1) == sorted(hn) == list(range(len(rr1)))
+    for it in h1:
+        assert len(hn[it]) == world and len(set(hn[it])) == 1, it  # all ranks hold the same scalar
+        assert abs(hn[it][0] - h1[it][0]) <= 1e-10 * h1[it][0], it
     # everything else the driver prints (header, flip line, [ECC] line, iteration count, errors)
     norm = lambda t: re.sub(r"(total error|max error) += +[0-9.]+", lambda m: m.group(0)[:-2], t).lstrip("\n")  # noqa: E731
     assert norm(rest1) == norm(restn)
@@ -258,3 +281,30 @@ def test_cpp_coo_driver_refuses_several_ranks_loudly():
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert p.returncode == 2
     assert "shards CSR" in p.stderr and "ran for" not in p.stdout
+
+
+def test_config3_cli_sed_x_index_full_size():
+    """BASELINE.json configs[2] as it is spelled: cg-csr -t hip -m sed -x INDEX on the 50 M-nnz
+    Laplacian through the C++ driver (reference cg.cpp:254-274 -> CSR/CPUContext.cpp:135-159):
+    the flipped column word is caught by the first SpMV, the run ends with status 1."""
+    out = subprocess.run([exe("csr"), "-t", "hip", "-s", "laplace5:3162,3162", "-m", "sed", "-x", "INDEX", "--seed", "7",
+                          "-q"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 1, out.stdout[-600:] + out.stderr[-600:]
+    m = re.search(r"\*\*\* flipping bit (\d+) at index (\d+) \*\*\*\n", out.stdout)
+    assert m and 64 <= int(m.group(1)) < 96 and 0 <= int(m.group(2)) < 49978572
+    assert out.stdout.endswith("[ECC] error detected at index %s\n" % m.group(2))
+    assert "number of non-zeros   = 49978572 " in out.stdout and "ran for" not in out.stdout
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_run_benchmark_script(fmt):
+    """host/run_benchmark (reference run_benchmark:1-28): mean (min / max) of 'time taken' over
+    NUM_RUNS runs for every registered implementation."""
+    p = subprocess.run([os.path.join(HOST, "run_benchmark"), exe(fmt), "-f", MTX, "-b", "2"], capture_output=True,
+                       text=True, timeout=900, env=dict(os.environ, NUM_RUNS="2"))
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "across 2 runs" in p.stdout
+    rows = re.findall(r"^(hip-\w+) +: +([0-9.]+) ms   \( +([0-9.]+)  /  +([0-9.]+) \)$", p.stdout, re.M)
+    assert [r[0] for r in rows] == ["hip-" + m for m in ("none", "constraints", "sed", "sec7", "sec8", "secded", "sec")]
+    for _, mean, lo, hi in rows:
+        assert 0.0 < float(lo) <= float(mean) <= float(hi)

@@ -27,32 +27,38 @@ WORKER = os.path.join(HERE, "_gpu_dist_worker.py")
 
 
 def run_job(backend, world, matrix, mode, flip, fixed=0, env=None):
+    """One attempt.  A rank that hangs or dies fails the test with every rank's output
+    (a retry here would hide an intermittent hang in the RCCL / hipGraph path)."""
     idx, bit = flip if flip else (-1, 0)
-    last = None
     env = dict(os.environ, **(env or {}))
-    for attempt in range(2):
-        s = socket.socket()
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-        s.close()
-        procs = [subprocess.Popen([sys.executable, WORKER, backend, str(r), str(world), matrix, mode, str(idx),
-                                   str(bit), str(port), str(fixed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                  env=env)
-                 for r in range(world)]
-        outs = []
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen([sys.executable, WORKER, backend, str(r), str(world), matrix, mode, str(idx),
+                               str(bit), str(port), str(fixed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=env)
+             for r in range(world)]
+    outs, timed_out = [], False
+    for p in procs:
         try:
-            for p in procs:
-                outs.append(p.communicate(timeout=240))
+            outs.append(p.communicate(timeout=240))
         except subprocess.TimeoutExpired:
-            for p in procs:
-                p.kill()
-            last = "timeout"
-            continue
-        lines = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")]
-        if lines:
-            return json.loads(lines[-1][7:]), outs[0][0], [p.returncode for p in procs]
-        last = outs[0][0][-1500:] + outs[0][1][-3000:]
-    pytest.fail("job did not finish: %s" % last)
+            timed_out = True
+            break
+    if timed_out:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()  # exactly the processes started above
+        outs = [p.communicate() for p in procs]
+    tails = "\n".join("--- rank %d rc=%s\n%s\n%s" % (r, procs[r].returncode, o[-1500:], e[-3000:])
+                      for r, (o, e) in enumerate(outs))
+    if timed_out:
+        pytest.fail("rank job timed out after 240 s\n" + tails)
+    lines = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")]
+    if not lines:
+        pytest.fail("rank 0 printed no RESULT line\n" + tails)
+    return json.loads(lines[-1][7:]), outs[0][0], [p.returncode for p in procs]
 
 
 def oracle(matrix, mode, flip):

@@ -83,9 +83,11 @@ def test_python_cli_argument_handling_without_a_gpu():
     assert out.returncode == 1 and out.stdout == "Invalid convergence threshold\n"
     out = run_cli(["-t", "cpu"])
     assert out.returncode == 1 and "No implementation found for cpu-none" in out.stderr
-    out = run_cli(["-m", "nonsense"])
+    out = run_cli(["-m", "none"])  # default target is the reference's: cpu (cg.cpp:191)
+    assert out.returncode == 1 and "No implementation found for cpu-none" in out.stderr
+    out = run_cli(["-t", "hip", "-m", "nonsense"])
     assert out.returncode == 1 and "No implementation found for hip-nonsense" in out.stderr
-    out = run_cli(["-f", "/nonexistent.mtx"])
+    out = run_cli(["-t", "hip", "-f", "/nonexistent.mtx"])
     assert out.returncode == 1 and out.stdout == "Failed to open '/nonexistent.mtx'\n"
     out = run_cli(["--help"])
     assert out.returncode == 0 and "--inject-bitflip" in out.stdout and "--synthetic" in out.stdout

@@ -46,21 +46,8 @@ timeit("all_to_all_single", lambda: dist.all_to_all_single(b[:4096], a[:4096]))
 timeit("batch_isend_irecv (self)", p2p)
 timeit("all_to_all (lists)", lambda: dist.all_to_all([b[:3162]], [a[:3162]]))
 
-# the same window copy captured into a hipGraph and replayed
-try:
-    a.fill_(0.0)
-    b.fill_(-1.0)
-    p2p()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
-        p2p()
-    a.copy_(torch.arange(8192, dtype=torch.float64, device="cuda"))
-    g.replay()
-    torch.cuda.synchronize()
-    ok = bool((b[:3162] == a[:3162]).all())
-    print("batch_isend_irecv in a graph: replay %s" % ("copies the data" if ok else "DID NOT copy the data"), flush=True)
-    timeit("graph replay of it", g.replay)
-except Exception as e:  # noqa: BLE001
-    print("batch_isend_irecv in a graph failed: %s" % str(e)[:300], flush=True)
+# (A last leg used to capture the batch_isend_irecv window copy into a hipGraph.  On torch
+# 2.10 / RCCL 2.26 that ended the process with a core dump -- a native abort no try/except
+# here can catch; record: gpurun_out/p2p_cost.log of round 1, DESIGN.md section 5.  The
+# product never captures point-to-point copies, so the leg is gone rather than guarded.)
 dist.destroy_process_group()
