@@ -54,6 +54,7 @@ SIGNATURES = {
     "abft_hip_matrix_create_shard": (C.c_int, [vp, C.c_int, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int,
                                                C.c_int, C.c_uint32, vpp]),
     "abft_hip_matrix_destroy": (C.c_int, [vp]),
+    "abft_hip_matrix_info": (C.c_int, [vp, i32p, i32p]),
     "abft_hip_matrix_read_csr": (C.c_int, [vp, vp, vp, vp]),
     "abft_hip_matrix_read_coo": (C.c_int, [vp, vp]),
     "abft_hip_inject": (C.c_int, [vp, C.c_uint32, i32p, C.c_int]),

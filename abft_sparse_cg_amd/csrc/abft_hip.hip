@@ -649,6 +649,19 @@ extern "C" int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, in
   return ABFT_OK;
 }
 
+extern "C" int abft_hip_matrix_info(abft_hip_matrix *mat, int *layout, int *launches_per_spmv) {
+  if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
+  if (layout) *layout = mat->use_panels ? 1 : 0;
+  if (launches_per_spmv) {
+    int n = 1;
+    if (mat->use_panels && mat->panel_chunk && mat->panels.npanels)
+      n = (int)((mat->panels.npanels + mat->panel_chunk - 1) / mat->panel_chunk);
+    if (mat->fmt == ABFT_FMT_COO) n += 1;  // coo_fixup_kernel (returns at once on clean data)
+    *launches_per_spmv = n;
+  }
+  return ABFT_OK;
+}
+
 extern "C" int abft_hip_matrix_destroy(abft_hip_matrix *mat) {
   if (!mat) return ABFT_OK;
   if (int rc = bind(mat->ctx)) return rc;

@@ -42,6 +42,30 @@ struct CsrPanels {
   const uint16_t *seg_ptr;   // per segment ABFT_PANEL_ROWS + 1 row offsets relative to seg_base
   uint32_t ngroups, npanels;
 };
+// Sweep layout: the panel layout's successor (same idea: (output group, gather-index panel)
+// segments, outputs' additions in the caller's order) run as ONE persistent launch:
+//   * a workgroup owns a group of 256 * RPT outputs for the whole sweep; thread (wave w,
+//     lane l) keeps the running sums of outputs w*64*RPT + j*64 + l (j < RPT) in
+//     registers from the first panel to the last -- y is written once (the chunked panel
+//     launches carried the sums through y: 7 extra round trips of y on config 4);
+//   * per (segment, output) only a COUNT is stored (1 byte, 2 if any exceeds 255), laid out
+//     so that a thread loads its RPT counts with one access; the element offsets come from
+//     a DPP prefix scan over the wave plus one stored base per (segment, wave)
+//     (the 16-bit offset tables of the panel layout were 134 MB on config 4);
+//   * what keeps every workgroup of an XCD inside the same window of the gathered vector is
+//     not a kernel boundary but pacing: a workgroup starts panel step s only when all
+//     workgroups of its XCD have finished step s - LAG (arrival counters per XCD and step,
+//     relaxed atomics -- no data is handed over, so no fences; the wait is bounded, pacing
+//     is speed only, never correctness).
+struct SweepLayout {
+  const uint32_t *wbase;   // nseg * 4 + 1 : first element of (segment, wave); segment s = [wbase[4s], wbase[4s+4])
+  const uint8_t *counts;   // [segment][thread 0..255][j 0..RPT-1], 1 or 2 bytes each
+  uint32_t ngroups, npanels;
+  uint32_t *pace;          // [0] started, [1] finished, [2..10) members per XCD, then [xcd][step] arrivals
+  uint32_t pace_steps;     // steps per XCD the pace buffer has room for
+  uint32_t lag;            // 0: no pacing
+};
+
 #ifndef ABFT_CFG_PANEL_RPT
 #define ABFT_CFG_PANEL_RPT 8  // outputs per thread of the panel kernels (4: equal on config 4, -14% on config 5)
 #endif
@@ -169,6 +193,13 @@ struct FuseOut {
 struct TileSpan {
   uint32_t first, cut, skip, count;
 };
+
+// sweep-layout SpMV (modes other than constraints): panels [c0, c1) in one persistent launch of
+// `grid` workgroups (all resident); c0 > 0 resumes from the sums a previous launch left in y
+hipError_t launch_spmv_sweep(int fmt, int mode, int rpt, bool cnt16, const CsrDev &A, const CooDev &C,
+                             const SweepLayout &L, const double *x, double *y, EventRing ev, const FuseOut *fuse,
+                             uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s);
+int spmv_sweep_blocks_per_cu(int fmt, int mode, int rpt, bool cnt16);
 
 // panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
 hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,

@@ -941,6 +941,231 @@ hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y
   }
 }
 
+// ------------------------------------------------------------ sweep-layout SpMV --
+
+constexpr uint32_t PACE_HDR = 10;  // pace[0] started, [1] finished, [2..10) workgroups per XCD
+
+// which of the 8 XCDs (each with its own L2) this wave runs on
+__device__ __forceinline__ uint32_t xcc_id() {
+  uint32_t v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 7u;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+
+// inclusive prefix sum over the 64 lanes, entirely in the VALU (same steps as wave_sum:
+// Hillis-Steele inside each 16-lane row, then the row totals carried across)
+__device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
+  v += dpp_u32<0x111, 0xf>(v);
+  v += dpp_u32<0x112, 0xf>(v);
+  v += dpp_u32<0x114, 0xf>(v);
+  v += dpp_u32<0x118, 0xf>(v);
+  v += dpp_u32<0x142, 0xa>(v);
+  v += dpp_u32<0x143, 0xc>(v);
+  return v;
+}
+
+// Pacing (speed only): wait, bounded, until every workgroup of this XCD has finished
+// step `idx`.  Relaxed agent-scope loads (L1 bypass); nothing is handed over, so no fence.
+__device__ __noinline__ void pace_wait(const uint32_t *pace, uint32_t xcd, uint32_t steps, uint32_t idx, uint32_t grid) {
+  for (int it = 0; it < 4096; it++) {
+    if (__hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= grid) {  // every workgroup has registered
+      const uint32_t m = __hip_atomic_load(pace + 2u + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t v = __hip_atomic_load(pace + PACE_HDR + xcd * steps + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v >= m) return;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
+// Sweep-layout SpMV, CSR and COO (see SweepLayout).  Stages a segment tile by tile through
+// LDS with the same branch-free load phase as the streaming kernels (ECC in registers,
+// cold path out of line); each thread then adds the staged products of its outputs, in
+// element order, onto its running sums -- an output's additions happen in the caller's
+// order (panels ascend, and inside a panel its elements keep their order), so y stays
+// bit-identical to the reference (CSR/CPUContext.cpp:115-133 and variants, COO :104-121).
+template <int FMT, int MODE, int RPT, bool CNT16>
+__global__ __launch_bounds__(ABFT_BLOCK) void spmv_sweep_kernel(CsrDev A, CooDev C, SweepLayout L,
+                                                                const double *__restrict__ x, double *__restrict__ y,
+                                                                EventRing ev, FuseOut fuse, bool fused, uint32_t c0,
+                                                                uint32_t c1) {
+  constexpr int EPT = FMT == FMT_CSR ? ABFT_CFG_PANEL_EPT : ABFT_COO_EPT;
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT, GROUP = 256u * RPT, CB = CNT16 ? 2u : 1u;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[FMT == FMT_COO ? TILE : 2];
+  __shared__ uint32_t s_last;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_out = FMT == FMT_CSR ? A.n_out : C.n_out;
+  const uint32_t nsteps = c1 - c0;
+  const uint32_t nrounds = (L.ngroups + gridDim.x - 1u) / gridDim.x;
+  const bool pace = L.lag != 0u && nsteps * nrounds <= L.pace_steps;
+  uint32_t xcd = 0;
+  if (pace) {
+    xcd = xcc_id();
+    if (threadIdx.x == 0) {
+      __hip_atomic_fetch_add(L.pace + 2u + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(L.pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  double dsum = 0.0;
+  for (uint32_t round = 0; round < nrounds; round++) {
+    const uint32_t g = blockIdx.x + round * gridDim.x;
+    if (g >= L.ngroups) {  // the last round may be short: still arrive, others of this XCD count on it
+      if (pace && threadIdx.x == 0)
+        for (uint32_t k = 0; k < nsteps; k++)
+          __hip_atomic_fetch_add(L.pace + PACE_HDR + xcd * L.pace_steps + round * nsteps + k, 1u, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    const uint32_t out0 = g * GROUP + wave * (64u * RPT) + lane;  // this thread's outputs: out0 + 64 j
+    double acc[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + 64u * (uint32_t)j;
+      acc[j] = (c0 > 0 && o < n_out) ? y[o] : 0.0;
+    }
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t seg = g * L.npanels + c;
+      const uint32_t step = round * nsteps + (c - c0);
+      const uint32_t e0 = L.wbase[4u * seg], e1 = L.wbase[4u * seg + 4u];
+      if (e0 != e1) {  // uniform
+        // ---- this thread's RPT counts -> element ranges of its outputs in this segment ----
+        uint32_t cw[RPT * CB / 4];
+        {
+          const uint32_t *cp = reinterpret_cast<const uint32_t *>(L.counts + ((size_t)seg * 256u + threadIdx.x) * (RPT * CB));
+#pragma unroll
+          for (int k = 0; k < (int)(RPT * CB / 4); k++) cw[k] = cp[k];
+        }
+        uint32_t start[RPT];
+        uint32_t run = L.wbase[4u * seg + wave];  // wave-uniform
+        if (!CNT16) {
+#pragma unroll
+          for (int m = 0; m < RPT / 2; m++) {  // two 8-bit counts per scan, in 16-bit halves (64 * 255 < 65536)
+            const uint32_t b0 = (cw[m / 2] >> (16 * (m & 1))) & 0xffu, b1 = (cw[m / 2] >> (16 * (m & 1) + 8)) & 0xffu;
+            const uint32_t inc = wave_scan_u32(b0 | (b1 << 16));
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            start[2 * m] = run + (inc & 0xffffu) - b0;
+            run += tot & 0xffffu;
+            start[2 * m + 1] = run + (inc >> 16) - b1;
+            run += tot >> 16;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < RPT; j++) {
+            const uint32_t cj = (cw[j / 2] >> (16 * (j & 1))) & 0xffffu;
+            const uint32_t inc = wave_scan_u32(cj);
+            start[j] = run + inc - cj;
+            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+          }
+        }
+        if (pace && step >= L.lag && threadIdx.x == 0)
+          pace_wait(L.pace, xcd, L.pace_steps, step - L.lag, gridDim.x);
+        for (uint32_t lo = e0; lo < e1;) {
+          const uint32_t b = FMT == FMT_CSR ? (lo & ~1u) : lo;
+          const uint32_t hi = min(e1, b + TILE);
+          __syncthreads();
+          if (FMT == FMT_CSR) csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+          else coo_stage<MODE, EPT>(C, x, ev, lo, hi, s_prod, s_col);
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < RPT; j++) {
+            const uint32_t cj = CNT16 ? (cw[j / 2] >> (16 * (j & 1))) & 0xffffu : (cw[j / 4] >> (8 * (j & 3))) & 0xffu;
+            const uint32_t a0 = max(start[j], lo), a1 = min(start[j] + cj, hi);
+            if (a0 < a1) {
+              double t = acc[j];
+              if (FMT == FMT_CSR) csr_row_sum<MODE>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
+              else lds_ordered_add(C, ev, s_prod, s_col, a0 - lo, a1 - lo, out0 + 64u * (uint32_t)j, lo, t);
+              acc[j] = t;
+            }
+          }
+          lo = hi;
+        }
+      }
+      if (pace && threadIdx.x == 0)
+        __hip_atomic_fetch_add(L.pace + PACE_HDR + xcd * L.pace_steps + step, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + 64u * (uint32_t)j;
+      if (o < n_out) {
+        y[o] = acc[j];
+        if (fused) dsum += x[fuse.x_off + o] * acc[j];
+      }
+    }
+  }
+  if (fused) fused_dot_finish(dsum, fuse, blockIdx.x);
+  if (pace) {
+    // the workgroup that leaves last clears the counters for the next launch
+    if (threadIdx.x == 0)
+      s_last = __hip_atomic_fetch_add(L.pace + 1u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    __syncthreads();
+    if (s_last)
+      for (uint32_t i = threadIdx.x; i < PACE_HDR + 8u * L.pace_steps; i += ABFT_BLOCK)
+        __hip_atomic_store(L.pace + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int FMT, int MODE, int RPT, bool CNT16>
+static hipError_t launch_sweep_inst(const CsrDev &A, const CooDev &C, const SweepLayout &L, const double *x, double *y,
+                                    EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1,
+                                    hipStream_t s) {
+  hipLaunchKernelGGL((spmv_sweep_kernel<FMT, MODE, RPT, CNT16>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A, C, L, x, y, ev,
+                     fuse ? *fuse : FuseOut{}, fuse != nullptr, c0, c1);
+  return hipGetLastError();
+}
+
+template <int FMT, int MODE, int RPT, bool CNT16> static int sweep_occupancy_inst() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_sweep_kernel<FMT, MODE, RPT, CNT16>, ABFT_BLOCK, 0) !=
+          hipSuccess || n < 1)
+    n = 1;
+  return n > 8 ? 8 : n;
+}
+
+// one switch for both uses: OP(FMT, MODE, RPT, CNT16)
+#define ABFT_SWEEP_DISPATCH(OP)                                                                      \
+  do {                                                                                               \
+    const int key = (fmt == FMT_COO ? 1000 : 0) + mode * 100 + (rpt == 16 ? 10 : 0) + (cnt16 ? 1 : 0); \
+    switch (key) {                                                                                   \
+      ABFT_SWEEP_CASES(OP, FMT_CSR, 0) ABFT_SWEEP_CASES(OP, FMT_COO, 1000)                           \
+      default: break;                                                                                \
+    }                                                                                                \
+  } while (0)
+#define ABFT_SWEEP_CASES(OP, F, K)                                                          \
+  ABFT_SWEEP_MODE(OP, F, K, MODE_NONE) ABFT_SWEEP_MODE(OP, F, K, MODE_SED) ABFT_SWEEP_MODE(OP, F, K, MODE_SEC7) \
+  ABFT_SWEEP_MODE(OP, F, K, MODE_SEC8) ABFT_SWEEP_MODE(OP, F, K, MODE_SECDED)
+#define ABFT_SWEEP_MODE(OP, F, K, M)                      \
+  case K + M * 100 + 0: OP(F, M, 8, false); break;        \
+  case K + M * 100 + 1: OP(F, M, 8, true); break;         \
+  case K + M * 100 + 10: OP(F, M, 16, false); break;      \
+  case K + M * 100 + 11: OP(F, M, 16, true); break;
+
+hipError_t launch_spmv_sweep(int fmt, int mode, int rpt, bool cnt16, const CsrDev &A, const CooDev &C,
+                             const SweepLayout &L, const double *x, double *y, EventRing ev, const FuseOut *fuse,
+                             uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+  if (L.ngroups == 0 || c0 >= c1) return hipSuccess;
+  if (c1 > L.npanels || grid == 0 || (rpt != 8 && rpt != 16)) return hipErrorInvalidValue;
+  hipError_t e = hipErrorInvalidValue;
+#define ABFT_OP(F, M, R, W) e = launch_sweep_inst<F, M, R, W>(A, C, L, x, y, ev, fuse, grid, c0, c1, s)
+  ABFT_SWEEP_DISPATCH(ABFT_OP);
+#undef ABFT_OP
+  return e;
+}
+
+int spmv_sweep_blocks_per_cu(int fmt, int mode, int rpt, bool cnt16) {
+  int n = 1;
+#define ABFT_OP(F, M, R, W) n = sweep_occupancy_inst<F, M, R, W>()
+  ABFT_SWEEP_DISPATCH(ABFT_OP);
+#undef ABFT_OP
+  return n;
+}
+
 // ------------------------------------------------- COO: corrupted-column fix-up --
 
 // Launched behind every COO SpMV (one workgroup; returns at once when the SpMV queued

@@ -47,7 +47,20 @@ def parse():
                     help="N > 1: return both scalars to the host every iteration (default: device-resident)")
     ap.add_argument("--no-probe", dest="probe", action="store_false",
                     help="skip the streaming-copy bandwidth probe (the measured-peak denominator beside 8 TB/s)")
+    ap.add_argument("--no-extras", dest="extras", action="store_false",
+                    help="N = 1: skip the short legs on the other BASELINE.json configurations")
     return ap.parse_args()
+
+
+# The other single-GPU configurations of BASELINE.json (north_star's SpMV+ECC target is quoted
+# on the first two), each run as a short leg AFTER the headline's timed loop:
+# (key, spec, fmt, mode, BASELINE.json config it stands for)
+EXTRA_LEGS = [
+    ("config2_sed", "laplace5:3162,3162", "csr", "sed", "configs[2] matrix, -m sed, fault-free (detection itself: tests)"),
+    ("config2_secded", "laplace5:3162,3162", "csr", "secded", "configs[1] matrix, -m secded"),
+    ("config4_shard1", "random:4194304,24,1", "csr", "secded", "configs[3] matrix (100 M nnz) on ONE GPU"),
+    ("config5", "powerlaw:2097152,2", "coo", "sec7", "configs[4]: cg-coo -m sec (= sec7)"),
+]
 
 
 def spmv_bytes(fmt, n, nnz):
@@ -65,6 +78,62 @@ def traffic_from_profile(workload):
         return None
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def extra_leg(spec, fmt, mode, triplets=None, iters=32, warm=4):
+    """One short leg: `iters` CG iterations with EVERY SpMV bracketed by HIP events on the
+    context's stream.  -> dict for the bench line."""
+    import numpy as np
+
+    import abft_sparse_cg_amd as amd
+    from abft_sparse_cg_amd import capi, generators
+    from abft_sparse_cg_amd.context import fdiv
+
+    cols, rows, vals, n = triplets if triplets else generators.generate(spec)
+    nnz = len(vals)
+    ctx = amd.HIPContext(mode, fmt, device=0)
+    A = ctx.create_matrix(cols, rows, vals, n, nnz)
+    layout, launches = ctx.matrix_info(A)
+    b, x, r, p, w = (ctx.create_vector(n) for _ in range(5))
+    ctx.upload(b, generators.reference_rhs(n))
+    ctx.upload(x, np.zeros(n))
+    ctx.copy_vector(r, b)
+    ctx.copy_vector(p, r)
+    rr = ctx.dot(r, r)
+    t0 = None
+    for it in range(warm + iters):
+        if it == warm:
+            ctx.profile(1 << capi.K_SPMV, stride=1)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+        ctx.spmv(A, p, w)
+        alpha = fdiv(rr, ctx.dot(p, w))
+        rr_new = ctx.calc_xr(x, r, p, w, alpha)
+        ctx.calc_p(p, r, fdiv(rr_new, rr))
+        rr = rr_new
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ms, cnt = ctx.profile_read(capi.K_SPMV)
+    ctx.close()
+    us = ms * 1e3 / max(cnt, 1)
+    byts = spmv_bytes(fmt, n, nnz)
+    ach = byts / us / 1e3
+    return {"workload": "cg-%s -t hip -m %s, synthetic %s" % (fmt, mode, spec), "N": n, "nnz": nnz, "layout": layout,
+            "sampled_spmvs": cnt, "avg_spmv_us": round(us, 2), "launches_per_spmv": launches,
+            "avg_launch_us": round(us / launches, 2), "algorithmic_bytes_per_spmv": byts,
+            "achieved": round(ach, 1), "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "traffic": traffic_from_profile("%s/%s/%s" % (spec, fmt, mode)),
+            "it_per_s_with_brackets": round(iters / dt, 1)}
+
+
 def single(args):
     import numpy as np
     import torch
@@ -78,7 +147,7 @@ def single(args):
     ctx = amd.HIPContext(args.mode, args.fmt, device=0)
     A = ctx.create_matrix(cols, rows, vals, n, nnz)
     b, x, r, p, w = (ctx.create_vector(n) for _ in range(5))
-    ctx.upload(b, np.random.default_rng(1).random(n))
+    ctx.upload(b, generators.reference_rhs(n))  # glibc rand(), default seed: the reference's b (cg.cpp:66-74)
     ctx.upload(x, np.zeros(n))
     ctx.copy_vector(r, b)
     ctx.copy_vector(p, r)
@@ -95,9 +164,11 @@ def single(args):
     for _ in range(args.warmup):
         step()
     if not args.no_profile:
-        # HIP-event brackets inside the timed region; every 4th SpMV launch is sampled
-        # (a bracket serialises the launches around it: sampling all of them costs ~3 %)
-        ctx.profile(0xF if args.profile_all else 1 << capi.K_SPMV, stride=1 if args.profile_all else 4)
+        # HIP-event brackets inside the timed region on sampled SpMV launches (a bracket
+        # serialises the launches around it: sampling all of them costs ~3 %): every 4th,
+        # or more often when the run is short, so that at least ~25 launches are averaged
+        stride = 1 if args.profile_all else max(1, min(4, args.steps // 25))
+        ctx.profile(0xF if args.profile_all else 1 << capi.K_SPMV, stride=stride)
     ctx.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -144,6 +215,19 @@ def single(args):
     rr_final = state["rr"]
     ctx.close()
 
+    # ---- the other single-GPU configurations, outside the headline's timed loop ----
+    extras = None
+    if args.extras and not args.no_profile:
+        extras = {}
+        for key, spec, fmt, mode, what in EXTRA_LEGS:
+            same = spec == args.spec
+            try:
+                leg = extra_leg(spec, fmt, mode, (cols, rows, vals, n) if same else None)
+                leg["stands_for"] = what
+            except Exception as e:  # noqa: BLE001 -- a leg that cannot run is reported, not hidden
+                leg = {"error": repr(e)[:300], "stands_for": what}
+            extras[key] = leg
+
     cpu = None
     if args.cpu_iters > 0 and args.fmt == "csr":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -151,12 +235,17 @@ def single(args):
         res = baseline.time_cg(cols, rows, vals, n, args.mode, args.cpu_iters)
         one = baseline.time_cg(cols, rows, vals, n, args.mode, max(args.cpu_iters // 8, 2), threads=1)
         cpu = {"value": round(res["it_per_s"], 3), "unit": "CG iterations/s", "cores": res["cores"],
-               "kind": res["kind"],
+               "cpu_model": cpu_model(), "kind": res["kind"],
                "sample": "%d CG iterations of the same matrix (%s, -m %s), OpenMP spmv + serial vector ops as the "
                          "reference, %.1f s" % (res["iters"], args.spec, args.mode, res["seconds"]),
                "one_core": {"value": round(one["it_per_s"], 3), "cores": 1,
                             "sample": "%d iterations, %.1f s" % (one["iters"], one["seconds"])}}
-    return dt, n, nnz, roof, kernels, cpu, probe, rr_final
+        if args.extras and args.mode != "secded":
+            sec = baseline.time_cg(cols, rows, vals, n, "secded", max(args.cpu_iters // 2, 2))
+            cpu["secded"] = {"value": round(sec["it_per_s"], 3), "cores": sec["cores"],
+                             "sample": "%d iterations of the same matrix with -m secded, %.1f s"
+                                       % (sec["iters"], sec["seconds"])}
+    return dt, n, nnz, roof, kernels, cpu, probe, rr_final, extras
 
 
 def sharded(args):
@@ -188,7 +277,7 @@ def sharded(args):
     eng = HipEngine(args.mode, "csr", device=local)
     cg = ShardedCG(eng, cols, rows, vals, bounds, sum(counts[:rank]), args.mode)
     del cols, rows, vals
-    b_local = np.random.default_rng(1).random(n)[r0:r1]
+    b_local = generators.reference_rhs(n)[r0:r1]
     cg.set_rhs(b_local)
     # -c 0 run: alpha and beta stay on the device (ShardedCG.run_fixed), so an
     # iteration is enqueue-only; --host-scalars times the loop that returns both
@@ -257,7 +346,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic"}
     if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("ABFT_BENCH_SHARDED") != "1":
-        dt, n, nnz, roof, kernels, cpu, probe, rr = single(args)
+        dt, n, nnz, roof, kernels, cpu, probe, rr, extras = single(args)
         out = dict(base)
         out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
                     "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec)
@@ -267,6 +356,8 @@ def main():
                     "roofline": roof, "cpu_baseline": cpu, "kernels": kernels})
         if probe:
             out["stream_probe"] = probe
+        if extras:
+            out["extra_legs"] = extras
         print(json.dumps(out))
         return
     rank, dt, n, nnz, roof, kernels, rr, exchange, loop = sharded(args)

@@ -36,6 +36,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def _reference_rhs(n):
+    """glibc rand() / RAND_MAX with the default seed: the reference driver's b (cg.cpp:66-74)"""
+    import sys
+    root = os.path.dirname(HERE)
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from abft_sparse_cg_amd import generators
+    return generators.reference_rhs(n)
+
+
 def time_cg(cols, rows, vals, n, mode, iters, threads=None):
     """-> dict(kind, iters, seconds, it_per_s, cores).  Runs `iters` CG iterations
     (conv threshold 0) from x=0, b = deterministic rhs."""
@@ -48,7 +58,7 @@ def time_cg(cols, rows, vals, n, mode, iters, threads=None):
     cols = np.ascontiguousarray(cols, dtype=np.uint32)
     rows = np.ascontiguousarray(rows, dtype=np.uint32)
     vals = np.ascontiguousarray(vals, dtype=np.float64)
-    b = np.random.default_rng(1).random(n)
+    b = _reference_rhs(n)
     x = np.zeros(n)
     r, p, w = np.empty(n), np.empty(n), np.empty(n)
     hist = np.zeros(max(iters, 1))
