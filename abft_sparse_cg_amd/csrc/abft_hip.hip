@@ -92,6 +92,10 @@ struct abft_hip_matrix {
   CsrPanels panels{};
   uint32_t panel_grid = 0;          // workgroups of the panel kernel
   uint32_t panel_chunk = 0;         // panels per launch (0 = all)
+  bool use_sweep = false;           // sweep layout (one persistent launch; see SweepLayout)
+  SweepLayout sweep{};
+  int sweep_rpt = 8;
+  uint32_t sweep_grid = 0;
   // streaming CSR: host copy of the row-block descriptors, and the tiles [t_lo, t_hi)
   // made of interior rows only (abft_hip_matrix_set_interior; empty by default)
   std::vector<uint4> blk_host;
@@ -303,6 +307,12 @@ static int dev_upload(abft_hip_matrix *m, T **dst, const T *src, size_t count, s
 
 static void matrix_free(abft_hip_matrix *m) {
   if (!m) return;
+  if (m->use_sweep && m->sweep.debug) {
+    uint32_t d[4] = {0, 0, 0, 0};
+    if (hipMemcpy(d, m->sweep.debug, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "sweep pacing: %u workgroup exits, %u waits, %u unsuccessful polls (lag %u, %u panels, grid %u)\n",
+              d[2], d[1], d[0], m->sweep.lag, m->sweep.npanels, m->sweep_grid);
+  }
   for (void *p : m->allocs) (void)hipFree(p);
   delete m;
 }
@@ -361,7 +371,7 @@ struct PanelBuild {
 static bool plan_panels(int mode, const uint32_t *in_idx, const uint32_t *out_idx, int n_out, int n_in, int nnz,
                         PanelBuild &pb) {
   const char *env = getenv("ABFT_HIP_LAYOUT");
-  const bool force = env && !strcmp(env, "panels");
+  const bool force = env && (!strcmp(env, "panels") || !strcmp(env, "sweep"));  // (sweep: CSR only, 1-byte counts)
   if ((env && !strcmp(env, "stream")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0) return false;
   uint32_t width = 1u << 18;  // 2 MB of x per panel; two panels per launch (ABFT_HIP_PANEL_CHUNK)
   if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
@@ -413,6 +423,135 @@ static bool plan_panels(int mode, const uint32_t *in_idx, const uint32_t *out_id
   return true;
 }
 
+// ---- sweep layout planning (host) ------------------------------------------------
+struct SweepBuild {
+  uint32_t ngroups = 0, npanels = 0, width = 0;
+  int rpt = 8;
+  std::vector<uint32_t> wbase;     // nseg * 4 + 1
+  std::vector<uint8_t> counts;     // [segment][thread][j]
+  std::vector<uint32_t> pos, orig; // caller's index -> storage position and back
+};
+
+// Same decision as plan_panels (scattered columns over a vector much larger than an XCD's
+// L2; a row's columns non-decreasing in the caller's order), then the sweep layout's arrays
+// (CSR: the caller's order is row-major).  `capacity(rpt)`: workgroups of the kernel variant
+// with `rpt` rows per thread that can be resident at once.  ABFT_HIP_LAYOUT=sweep forces it,
+// ABFT_HIP_PANEL_WIDTH / ABFT_HIP_SWEEP_RPT override the geometry.
+template <typename Cap>
+static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int n_out, int n_in, int nnz, Cap capacity,
+                       SweepBuild &sb) {
+  const char *env = getenv("ABFT_HIP_LAYOUT");
+  const bool force = env && !strcmp(env, "sweep");
+  if ((env && strcmp(env, "sweep") && strcmp(env, "auto")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0)
+    return false;
+  uint32_t width = 1u << 17;  // entries of the gathered vector per panel: 1 MB (2 MB: 757 vs 743 us on config 4)
+  if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
+  if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
+  const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
+  if (npanels == 0 || (uint64_t)n_out * npanels > ((uint64_t)1 << 31)) return false;
+  // one count per (row, panel) must stay small next to the matrix itself
+  if (!force && (uint64_t)n_out * npanels > (uint64_t)nnz * 3u) return false;
+  auto panel_of = [&](int i) { return std::min<uint64_t>(cols[i] / width, npanels - 1); };
+  for (int i = 1; i < nnz; i++)
+    if (rows[i] == rows[i - 1] && cols[i] < cols[i - 1]) return false;  // would reorder a row's additions
+  std::vector<uint8_t> rc((size_t)n_out * npanels, 0);  // elements per (row, panel)
+  for (int i = 0; i < nnz; i++) {
+    uint8_t &c = rc[(size_t)rows[i] * npanels + panel_of(i)];
+    if (c == 255u) return false;  // one-byte counts: such a matrix keeps the panel layout
+    c++;
+  }
+  if (!force) {  // a row group that stays within a panel or two is banded: streaming layout
+    const uint64_t g2k = ((uint64_t)n_out + 2047) / 2048;
+    uint64_t nonempty = 0;
+    std::vector<char> seen(npanels);
+    for (uint64_t g = 0; g < g2k; g++) {
+      std::fill(seen.begin(), seen.end(), 0);
+      const uint64_t r1 = std::min<uint64_t>((g + 1) * 2048, (uint64_t)n_out);
+      for (uint64_t r = g * 2048; r < r1; r++)
+        for (uint64_t c = 0; c < npanels; c++) seen[c] |= rc[r * npanels + c] != 0;
+      for (uint64_t c = 0; c < npanels; c++) nonempty += seen[c];
+    }
+    if (nonempty < 3 * g2k) return false;
+  }
+  // rows per thread: the smallest group size whose groups are all resident at once
+  sb.rpt = 16;
+  for (int rpt : {2, 4, 8})
+    if (((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt) <= capacity(rpt)) { sb.rpt = rpt; break; }
+  if (const char *r = getenv("ABFT_HIP_SWEEP_RPT")) {
+    const int v = atoi(r);
+    if (v == 2 || v == 4 || v == 8 || v == 16) sb.rpt = v;
+  }
+  const uint32_t G = 256u * (uint32_t)sb.rpt, WR = 64u * (uint32_t)sb.rpt;
+  const uint64_t ngroups = ((uint64_t)n_out + G - 1) / G, nseg = ngroups * npanels;
+  if (nseg > ((uint64_t)1 << 26)) return false;
+  sb.ngroups = (uint32_t)ngroups; sb.npanels = (uint32_t)npanels; sb.width = width;
+  // element ranges: per (segment, wave) base, per (segment, thread, j) count
+  sb.wbase.assign(nseg * 4 + 1, 0);
+  sb.counts.assign((size_t)nseg * 256u * sb.rpt + 16, 0);
+  uint64_t run = 0;
+  for (uint64_t g = 0; g < ngroups; g++)
+    for (uint64_t c = 0; c < npanels; c++) {
+      const uint64_t seg = g * npanels + c;
+      for (uint32_t w = 0; w < 4; w++) {
+        sb.wbase[seg * 4 + w] = (uint32_t)run;
+        for (uint32_t j = 0; j < (uint32_t)sb.rpt; j++)
+          for (uint32_t l = 0; l < 64; l++) {
+            const uint64_t row = g * G + w * WR + j * 64 + l;
+            const uint32_t k = row < (uint64_t)n_out ? rc[row * npanels + c] : 0u;
+            sb.counts[(seg * 256u + w * 64u + l) * sb.rpt + j] = (uint8_t)k;
+            run += k;
+          }
+      }
+    }
+  sb.wbase[nseg * 4] = (uint32_t)run;
+  // placement: rows ascending, a row's elements in the caller's order.  Inside a segment the
+  // rows follow the ownership order (wave, j, lane) = ascending local index, so filling the
+  // segments in row order lands every element at its place.
+  sb.pos.resize((size_t)nnz);
+  sb.orig.resize((size_t)nnz);
+  std::vector<uint32_t> fill(nseg, 0);
+  for (int i = 0; i < nnz; i++) {
+    const uint64_t seg = (uint64_t)(rows[i] / G) * npanels + panel_of(i);
+    const uint32_t p = sb.wbase[seg * 4] + fill[seg]++;
+    sb.pos[i] = p;
+    sb.orig[p] = (uint32_t)i;
+  }
+  return true;
+}
+
+static int finish_sweep(abft_hip_matrix *m, const SweepBuild &sb, uint32_t capacity) {
+  int rc;
+  uint32_t *d_wbase = nullptr, *d_pace = nullptr;
+  uint8_t *d_counts = nullptr;
+  if ((rc = dev_upload(m, &d_wbase, sb.wbase.data(), sb.wbase.size(), sb.wbase.size())) ||
+      (rc = dev_upload(m, &d_counts, sb.counts.data(), sb.counts.size(), sb.counts.size())))
+    return rc;
+  // all groups resident if they fit; else equal rounds
+  const uint32_t rounds = (sb.ngroups + capacity - 1) / capacity;
+  m->sweep_grid = (sb.ngroups + rounds - 1) / rounds;
+  std::vector<uint32_t> init(16 + 8 * 256, 0xffffffffu);  // PACE_HDR zeros + 8 boards of PACE_SLOTS "nobody here"
+  std::fill(init.begin(), init.begin() + 16, 0u);
+  if ((rc = dev_upload(m, &d_pace, init.data(), init.size(), init.size()))) return rc;
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));  // `init` goes out of scope
+  m->use_sweep = true;
+  m->sweep_rpt = sb.rpt;
+  m->sweep.wbase = d_wbase;
+  m->sweep.counts = d_counts;
+  m->sweep.ngroups = sb.ngroups;
+  m->sweep.npanels = sb.npanels;
+  m->sweep.pace = d_pace;
+  m->sweep.lag = 2;  // workgroups of an XCD spread over at most two consecutive panels
+  if (const char *e = getenv("ABFT_HIP_SWEEP_LAG")) m->sweep.lag = (uint32_t)std::max(0L, atol(e));
+  if (getenv("ABFT_HIP_SWEEP_DEBUG")) {  // pacing statistics, printed when the matrix is destroyed
+    uint32_t *d_dbg = nullptr;
+    const uint32_t z[4] = {0, 0, 0, 0};
+    if ((rc = dev_upload(m, &d_dbg, z, 4, 4))) return rc;
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    m->sweep.debug = d_dbg;
+  }
+  return ABFT_OK;
+}
+
 static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, const uint32_t *rows,
                       const double *values, int n_out, int n_in, int nnz, uint32_t index_base,
                       abft_hip_matrix **out) {
@@ -450,10 +589,33 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   uint32_t *d_rowptr = nullptr;
   uint4 *d_blk = nullptr;
 
-  // ---- layout: streaming row blocks (default) or column panels (scattered x) ----
+  // ---- layout: streaming row blocks (default), or for scattered x the sweep layout
+  // ---- (ABFT_HIP_LAYOUT=panels: its chunked-launch predecessor, kept for A/B runs) ----
+  SweepBuild sb;
+  auto cap = [&](int rpt) { return (uint64_t)spmv_sweep_blocks_per_cu(mode, rpt) * (uint64_t)ctx->num_cus; };
+  const bool sweep = plan_sweep(mode, columns, rows, n_out, n_in, nnz, cap, sb);
   PanelBuild pb;
-  const bool panels = plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);  // gather index = column, output = row
-  if (panels) {
+  const bool panels = !sweep && plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);
+  if (sweep) {
+    std::vector<uint32_t> pcols((size_t)nnz);
+    std::vector<double> pvals((size_t)nnz);
+    for (int i = 0; i < nnz; i++) {
+      pcols[sb.pos[i]] = columns[i];
+      pvals[sb.pos[i]] = values[i];
+    }
+    uint32_t *d_orig = nullptr, *d_pos = nullptr;
+    if ((rc = dev_upload(m, &A.cols, pcols.data(), (size_t)nnz, padded)) ||
+        (rc = dev_upload(m, &A.vals, pvals.data(), (size_t)nnz, padded)) ||
+        (rc = dev_upload(m, &d_orig, sb.orig.data(), (size_t)nnz, (size_t)nnz)) ||
+        (rc = dev_upload(m, &d_pos, sb.pos.data(), (size_t)nnz, (size_t)nnz)) ||
+        (rc = finish_sweep(m, sb, (uint32_t)cap(sb.rpt)))) {
+      matrix_free(m);
+      return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // pcols/pvals go out of scope
+    A.orig_index = d_orig;
+    A.pos_of_orig = d_pos;
+  } else if (panels) {
     std::vector<uint32_t> pcols((size_t)nnz);
     std::vector<double> pvals((size_t)nnz);
     for (int i = 0; i < nnz; i++) {
@@ -491,7 +653,7 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   }
   A.rowptr = d_rowptr;
   A.blk = d_blk;
-  if (!panels) m->blk_host = blk;
+  if (!panels && !sweep) m->blk_host = blk;
   hipError_t e = launch_encode_csr(mode, A.cols, A.vals, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host arrays may be freed on return
   if (e != hipSuccess) {
@@ -602,7 +764,8 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
   }
   if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
     // one partial per SpMV workgroup: row blocks (streaming) or output groups (panels)
-    const uint32_t max_parts = std::max(nblk, m->use_panels ? std::max(m->panel_grid, m->panels.ngroups) : 0u);
+    const uint32_t max_parts = std::max({nblk, m->use_panels ? std::max(m->panel_grid, m->panels.ngroups) : 0u,
+                                         m->use_sweep ? m->sweep_grid : 0u});
     if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(max_parts, 1) * sizeof(double)) != hipSuccess) {
       matrix_free(m);
       *out = nullptr;
@@ -651,7 +814,7 @@ extern "C" int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, in
 
 extern "C" int abft_hip_matrix_info(abft_hip_matrix *mat, int *layout, int *launches_per_spmv) {
   if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
-  if (layout) *layout = mat->use_panels ? 1 : 0;
+  if (layout) *layout = mat->use_sweep ? 2 : mat->use_panels ? 1 : 0;
   if (launches_per_spmv) {
     int n = 1;
     if (mat->use_panels && mat->panel_chunk && mat->panels.npanels)
@@ -677,7 +840,7 @@ extern "C" int abft_hip_matrix_read_csr(abft_hip_matrix *mat, uint32_t *cols, ui
   hipStream_t s = mat->ctx->stream;
   const CsrDev &A = mat->csr;
   if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, A.rowptr, ((size_t)A.n_out + 1) * 4, hipMemcpyDeviceToHost, s));
-  if (!mat->use_panels) {
+  if (!mat->use_panels && !mat->use_sweep) {
     if (cols && A.nnz) HIPCHK(hipMemcpyAsync(cols, A.cols, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
     if (values && A.nnz) HIPCHK(hipMemcpyAsync(values, A.vals, (size_t)A.nnz * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1035,7 +1198,11 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   uint32_t nparts = mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk;
   {
     KernelTimer t(ctx, ABFT_K_SPMV);
-    if (mat->fmt == ABFT_FMT_CSR && mat->use_panels) {
+    if (mat->use_sweep) {
+      nparts = mat->sweep_grid;
+      HIPCHK(launch_spmv_sweep(mat->mode, mat->sweep_rpt, mat->csr, mat->sweep, vec->d, result->d, ctx->ring,
+                               do_fuse ? &fuse : nullptr, mat->sweep_grid, 0u, mat->sweep.npanels, ctx->stream));
+    } else if (mat->fmt == ABFT_FMT_CSR && mat->use_panels) {
       nparts = mat->panel_grid;
       HIPCHK(launch_spmv_csr_panels(mat->mode, mat->csr, mat->panels, vec->d, result->d, ctx->ring,
                                     do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));

@@ -48,22 +48,21 @@ struct CsrPanels {
 //     lane l) keeps the running sums of outputs w*64*RPT + j*64 + l (j < RPT) in
 //     registers from the first panel to the last -- y is written once (the chunked panel
 //     launches carried the sums through y: 7 extra round trips of y on config 4);
-//   * per (segment, output) only a COUNT is stored (1 byte, 2 if any exceeds 255), laid out
-//     so that a thread loads its RPT counts with one access; the element offsets come from
+//   * per (segment, row) only a COUNT is stored (1 byte; a matrix with more than 255 elements
+//     of one row in one panel keeps the panel layout), laid out so that a thread loads its
+//     RPT counts with one access; the element offsets come from
 //     a DPP prefix scan over the wave plus one stored base per (segment, wave)
 //     (the 16-bit offset tables of the panel layout were 134 MB on config 4);
 //   * what keeps every workgroup of an XCD inside the same window of the gathered vector is
-//     not a kernel boundary but pacing: a workgroup starts panel step s only when all
-//     workgroups of its XCD have finished step s - LAG (arrival counters per XCD and step,
-//     relaxed atomics -- no data is handed over, so no fences; the wait is bounded, pacing
-//     is speed only, never correctness).
+//     not a kernel boundary but pacing through a per-XCD progress board (kernels.hip,
+//     board_load): speed only, never correctness; every wait is bounded.
 struct SweepLayout {
   const uint32_t *wbase;   // nseg * 4 + 1 : first element of (segment, wave); segment s = [wbase[4s], wbase[4s+4])
-  const uint8_t *counts;   // [segment][thread 0..255][j 0..RPT-1], 1 or 2 bytes each
+  const uint8_t *counts;   // [segment][thread 0..255][j 0..RPT-1], one byte each
   uint32_t ngroups, npanels;
-  uint32_t *pace;          // [0] started, [1] finished, [2..10) members per XCD, then [xcd][step] arrivals
-  uint32_t pace_steps;     // steps per XCD the pace buffer has room for
-  uint32_t lag;            // 0: no pacing
+  uint32_t *pace;          // exit ticket, registrations per XCD, a progress board per XCD (kernels.hip: PACE_*)
+  uint32_t lag;            // workgroups of an XCD stay within `lag` panels of its slowest; 0: no pacing
+  uint32_t *debug;         // optional (ABFT_HIP_SWEEP_DEBUG): {polls that waited, waits, workgroup exits}, never reset
 };
 
 #ifndef ABFT_CFG_PANEL_RPT
@@ -113,6 +112,9 @@ struct CooDev {
 #endif
 #ifndef ABFT_CFG_PANEL_EPT
 #define ABFT_CFG_PANEL_EPT 8  // elements per thread per tile of the panel-layout kernel (4: -9%)
+#endif
+#ifndef ABFT_CFG_SWEEP_EPT
+#define ABFT_CFG_SWEEP_EPT 8  // CSR elements per thread per tile of the sweep kernel
 #endif
 #ifndef ABFT_CFG_SCHED_BARRIER
 #define ABFT_CFG_SCHED_BARRIER 1
@@ -196,10 +198,9 @@ struct TileSpan {
 
 // sweep-layout SpMV (modes other than constraints): panels [c0, c1) in one persistent launch of
 // `grid` workgroups (all resident); c0 > 0 resumes from the sums a previous launch left in y
-hipError_t launch_spmv_sweep(int fmt, int mode, int rpt, bool cnt16, const CsrDev &A, const CooDev &C,
-                             const SweepLayout &L, const double *x, double *y, EventRing ev, const FuseOut *fuse,
-                             uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s);
-int spmv_sweep_blocks_per_cu(int fmt, int mode, int rpt, bool cnt16);
+hipError_t launch_spmv_sweep(int mode, int rpt, const CsrDev &A, const SweepLayout &L, const double *x, double *y,
+                             EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s);
+int spmv_sweep_blocks_per_cu(int mode, int rpt);  // rpt: 2, 4, 8 or 16
 
 // panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
 hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,
@@ -217,8 +218,8 @@ hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, cons
 hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);
 // behind every COO SpMV (and before the fold of a fused product): see MovedList
-hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y,
-                            EventRing ev, const FuseOut *fuse, hipStream_t s);
+hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, EventRing ev,
+                            const FuseOut *fuse, hipStream_t s);
 
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);

@@ -12,6 +12,8 @@
 // reference CPUContext (CSR/CPUContext.cpp:115-133); calc_xr/calc_p are
 // bit-identical element-wise; only the two reductions (tree order) differ from
 // the reference's serial sums, in the last bits.
+#include <type_traits>
+
 #include "abft_internal.h"
 #include "ecc_device.h"
 
@@ -331,7 +333,11 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
 #pragma unroll
   for (int j = 0; j < EPT; j++) {
     const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
+#ifdef ABFT_DBG_NOGATHER  // timing-only build: wrong results
+    xv[j] = (double)col[j];
+#else
     xv[j] = gather_load(x + (in ? col[j] : 0u));
+#endif
     if (!in) xv[j] = 0.0;
   }
   // no branch around the prefetch: with one, hipcc drains the whole memory queue
@@ -649,24 +655,35 @@ hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, cons
 // output the reference adds the product to (COO/CPUContext.cpp:120, :224, :267, :320,
 // :376) -- so that the summing phase can tell an element whose column no longer names
 // the group it is stored in (see MovedList).
-template <int MODE, int EPT>
-__device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restrict__ x,
-                                          const EventRing &ev, uint32_t lo, uint32_t hi,
-                                          double *s_prod, uint32_t *s_col) {
+template <int EPT> struct CooTileRegs {
   u32x4 e[EPT];
+};
+
+// the streaming loads of one COO tile [lo, hi): out-of-tile lanes re-read its first element
+template <int EPT>
+__device__ __forceinline__ void coo_issue_loads(const CooDev &A, uint32_t lo, uint32_t hi, CooTileRegs<EPT> &t) {
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
-    e[s] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
+    t.e[s] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
   }
   // (no scheduling barrier here, unlike csr_issue_loads: measured 3 % slower on this kernel)
+}
+
+// ECC, gathers, products and columns -> LDS for a tile whose loads were issued into `t`;
+// `prefetch`: the next tile's streaming loads go out right behind this tile's gathers.
+template <int MODE, int EPT>
+__device__ __forceinline__ void coo_consume(const CooDev &A, const double *__restrict__ x, const EventRing &ev,
+                                            uint32_t lo, uint32_t hi, const CooTileRegs<EPT> &t, double *s_prod,
+                                            uint32_t *s_col, bool prefetch, uint32_t nlo, uint32_t nhi,
+                                            CooTileRegs<EPT> &nxt) {
   uint32_t row[EPT];
   double val[EPT];
   bool ok[EPT];
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
-    uint32_t w[4] = {e[s].x, e[s].y, e[s].z, e[s].w};
+    uint32_t w[4] = {t.e[s].x, t.e[s].y, t.e[s].z, t.e[s].w};
     bool valid = j < hi;
     if (MODE == MODE_CONSTRAINTS) {
       if (valid) {  // per-element structural checks: a cold, gather-heavy mode by nature
@@ -699,14 +716,28 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const bool in = ok[s] && row[s] < A.n_in;
+#ifdef ABFT_DBG_NOGATHER  // timing-only build: wrong results
+    xv[s] = (double)row[s];
+#else
     xv[s] = gather_load(x + (in ? row[s] : 0u));
+#endif
     xv[s] = in ? xv[s] : 0.0;
   }
+  if (prefetch) coo_issue_loads<EPT>(A, nlo, nhi, nxt);
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const double p = val[s] * xv[s];
     s_prod[threadIdx.x + (uint32_t)s * ABFT_BLOCK] = ok[s] ? p : 0.0;
   }
+}
+
+template <int MODE, int EPT>
+__device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restrict__ x,
+                                          const EventRing &ev, uint32_t lo, uint32_t hi,
+                                          double *s_prod, uint32_t *s_col) {
+  CooTileRegs<EPT> t, unused;
+  coo_issue_loads<EPT>(A, lo, hi, t);
+  coo_consume<MODE, EPT>(A, x, ev, lo, hi, t, s_prod, s_col, false, 0u, 0u, unused);
 }
 
 // Cold: the product staged at LDS slot k (stored position j) belongs to output `col`,
@@ -943,7 +974,9 @@ hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y
 
 // ------------------------------------------------------------ sweep-layout SpMV --
 
-constexpr uint32_t PACE_HDR = 10;  // pace[0] started, [1] finished, [2..10) workgroups per XCD
+// pace buffer: [0] exit ticket, [1..9) workgroups registered per XCD, then per XCD a board of
+// PACE_SLOTS progress words (steps completed by the workgroup that drew that slot; ~0u = none)
+constexpr uint32_t PACE_HDR = 16, PACE_SLOTS = 256;
 
 // which of the 8 XCDs (each with its own L2) this wave runs on
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -969,131 +1002,167 @@ __device__ __forceinline__ uint32_t wave_scan_u32(uint32_t v) {
   return v;
 }
 
-// Pacing (speed only): wait, bounded, until every workgroup of this XCD has finished
-// step `idx`.  Relaxed agent-scope loads (L1 bypass); nothing is handed over, so no fence.
-__device__ __noinline__ void pace_wait(const uint32_t *pace, uint32_t xcd, uint32_t steps, uint32_t idx, uint32_t grid) {
-  for (int it = 0; it < 4096; it++) {
-    if (__hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= grid) {  // every workgroup has registered
-      const uint32_t m = __hip_atomic_load(pace + 2u + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t v = __hip_atomic_load(pace + PACE_HDR + xcd * steps + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (v >= m) return;
-    }
-    __builtin_amdgcn_s_sleep(16);
-  }
+// Pacing (speed only, never correctness).  What keeps the workgroups of an XCD inside one
+// window of the gathered vector -- so that the XCD's L2 serves the gathers -- is a progress
+// board per XCD: every workgroup publishes the number of panel steps it has completed with a
+// plain store (write-through to the XCD's L2) and reads the whole board of ITS XCD with one
+// wave-wide L1-bypassing load (256 words = 4 per lane), served by that same L2; the minimum
+// says how far the slowest workgroup of the XCD is.  Nothing crosses the fabric per step
+// (agent-scope atomics did: ~5 us each under load, measured, more than the misses cost),
+// no data is handed over (no fences), and every wait is bounded.
+struct BoardView { uint64_t a, b; };  // this lane's four progress words
+
+__device__ __forceinline__ BoardView board_load(const uint32_t *board, uint32_t lane) {
+  const uint64_t *p = reinterpret_cast<const uint64_t *>(board) + 2u * lane;
+  BoardView v;
+  v.a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
 }
 
-// Sweep-layout SpMV, CSR and COO (see SweepLayout).  Stages a segment tile by tile through
-// LDS with the same branch-free load phase as the streaming kernels (ECC in registers,
-// cold path out of line); each thread then adds the staged products of its outputs, in
-// element order, onto its running sums -- an output's additions happen in the caller's
-// order (panels ascend, and inside a panel its elements keep their order), so y stays
-// bit-identical to the reference (CSR/CPUContext.cpp:115-133 and variants, COO :104-121).
-template <int FMT, int MODE, int RPT, bool CNT16>
-__global__ __launch_bounds__(ABFT_BLOCK) void spmv_sweep_kernel(CsrDev A, CooDev C, SweepLayout L,
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_min_step(uint32_t v) {  // lanes without a source keep their own value
+  return min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false));
+}
+
+// minimum over the board (wave-uniform result)
+__device__ __forceinline__ uint32_t board_min(const BoardView &v) {
+  uint32_t m = min(min((uint32_t)v.a, (uint32_t)(v.a >> 32)), min((uint32_t)v.b, (uint32_t)(v.b >> 32)));
+  m = dpp_min_step<0x111>(m);  // row_shr 1, 2, 4, 8: lane 15 of each 16-lane row holds the row's minimum
+  m = dpp_min_step<0x112>(m);
+  m = dpp_min_step<0x114>(m);
+  m = dpp_min_step<0x118>(m);
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)m, 15), r1 = (uint32_t)__builtin_amdgcn_readlane((int)m, 31),
+                 r2 = (uint32_t)__builtin_amdgcn_readlane((int)m, 47), r3 = (uint32_t)__builtin_amdgcn_readlane((int)m, 63);
+  return min(min(r0, r1), min(r2, r3));
+}
+
+// Sweep-layout SpMV (CSR; see SweepLayout).  Stages a segment tile by tile through LDS with
+// the same branch-free load phase as the streaming kernel (ECC in registers, cold path out
+// of line); each thread then adds the staged products of its rows, in element order, onto
+// its running sums -- a row's additions happen in the caller's order (panels ascend, and
+// inside a panel its elements keep their order), so y stays bit-identical to the reference
+// (CSR/CPUContext.cpp:115-133 and variants).  RPT rows per thread: 256 * RPT rows per
+// workgroup, chosen at create time so that all groups are resident at once.
+template <int MODE, int RPT>
+__global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
                                                                 const double *__restrict__ x, double *__restrict__ y,
                                                                 EventRing ev, FuseOut fuse, bool fused, uint32_t c0,
                                                                 uint32_t c1) {
-  constexpr int EPT = FMT == FMT_CSR ? ABFT_CFG_PANEL_EPT : ABFT_COO_EPT;
-  constexpr uint32_t TILE = ABFT_BLOCK * EPT, GROUP = 256u * RPT, CB = CNT16 ? 2u : 1u;
+  constexpr int EPT = RPT <= 4 ? 4 : ABFT_CFG_SWEEP_EPT;  // small groups have small segments: smaller tiles
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT, GROUP = 256u * RPT;
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_col[FMT == FMT_COO ? TILE : 2];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
   __shared__ uint32_t s_last;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t n_out = FMT == FMT_CSR ? A.n_out : C.n_out;
   const uint32_t nsteps = c1 - c0;
   const uint32_t nrounds = (L.ngroups + gridDim.x - 1u) / gridDim.x;
-  const bool pace = L.lag != 0u && nsteps * nrounds <= L.pace_steps;
-  uint32_t xcd = 0;
+  const bool pace = L.lag != 0u;
+  uint32_t *board = nullptr;       // this XCD's progress board
+  uint32_t my_slot = 0xffffffffu;  // wave 0: where this workgroup publishes (only lane 0 stores)
   if (pace) {
-    xcd = xcc_id();
-    if (threadIdx.x == 0) {
-      __hip_atomic_fetch_add(L.pace + 2u + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(L.pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t xcd = xcc_id();
+    board = L.pace + PACE_HDR + xcd * PACE_SLOTS;
+    if (wave == 0u) {
+      uint32_t t = 0;
+      if (lane == 0u) t = __hip_atomic_fetch_add(L.pace + 1u + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      my_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      if (lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = 0u;
     }
   }
   double dsum = 0.0;
+  BoardView seen{~0ull, ~0ull};    // wave 0: the board as loaded one step ago
+  bool have_seen = false;
+  uint32_t dbg_spins = 0, dbg_waits = 0;
   for (uint32_t round = 0; round < nrounds; round++) {
     const uint32_t g = blockIdx.x + round * gridDim.x;
-    if (g >= L.ngroups) {  // the last round may be short: still arrive, others of this XCD count on it
-      if (pace && threadIdx.x == 0)
-        for (uint32_t k = 0; k < nsteps; k++)
-          __hip_atomic_fetch_add(L.pace + PACE_HDR + xcd * L.pace_steps + round * nsteps + k, 1u, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+    if (g >= L.ngroups) {  // the last round may be short: nobody of this XCD has to wait for us
+      if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;
       continue;
     }
-    const uint32_t out0 = g * GROUP + wave * (64u * RPT) + lane;  // this thread's outputs: out0 + 64 j
+    const uint32_t out0 = g * GROUP + wave * (64u * RPT) + lane;  // this thread's rows: out0 + 64 j
     double acc[RPT];
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + 64u * (uint32_t)j;
-      acc[j] = (c0 > 0 && o < n_out) ? y[o] : 0.0;
+      acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
     }
+    const uint32_t *wb = L.wbase + 4u * (size_t)g * L.npanels;
     for (uint32_t c = c0; c < c1; c++) {
-      const uint32_t seg = g * L.npanels + c;
       const uint32_t step = round * nsteps + (c - c0);
-      const uint32_t e0 = L.wbase[4u * seg], e1 = L.wbase[4u * seg + 4u];
+      const uint32_t e0 = wb[4u * c], e1 = wb[4u * c + 4u];
       if (e0 != e1) {  // uniform
-        // ---- this thread's RPT counts -> element ranges of its outputs in this segment ----
-        uint32_t cw[RPT * CB / 4];
+        // ---- this thread's RPT counts (one byte each) -> element ranges of its rows ----
+        uint32_t cw[RPT >= 4 ? RPT / 4 : 1];
         {
-          const uint32_t *cp = reinterpret_cast<const uint32_t *>(L.counts + ((size_t)seg * 256u + threadIdx.x) * (RPT * CB));
+          const uint8_t *cp = L.counts + ((size_t)(g * L.npanels + c) * 256u + threadIdx.x) * RPT;
+          if (RPT == 2) cw[0] = *reinterpret_cast<const uint16_t *>(cp);
+          else {
 #pragma unroll
-          for (int k = 0; k < (int)(RPT * CB / 4); k++) cw[k] = cp[k];
+            for (int k = 0; k < RPT / 4; k++) cw[k] = reinterpret_cast<const uint32_t *>(cp)[k];
+          }
         }
         uint32_t start[RPT];
-        uint32_t run = L.wbase[4u * seg + wave];  // wave-uniform
-        if (!CNT16) {
+        uint32_t run = wb[4u * c + wave];  // wave-uniform
 #pragma unroll
-          for (int m = 0; m < RPT / 2; m++) {  // two 8-bit counts per scan, in 16-bit halves (64 * 255 < 65536)
-            const uint32_t b0 = (cw[m / 2] >> (16 * (m & 1))) & 0xffu, b1 = (cw[m / 2] >> (16 * (m & 1) + 8)) & 0xffu;
-            const uint32_t inc = wave_scan_u32(b0 | (b1 << 16));
-            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            start[2 * m] = run + (inc & 0xffffu) - b0;
-            run += tot & 0xffffu;
-            start[2 * m + 1] = run + (inc >> 16) - b1;
-            run += tot >> 16;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < RPT; j++) {
-            const uint32_t cj = (cw[j / 2] >> (16 * (j & 1))) & 0xffffu;
-            const uint32_t inc = wave_scan_u32(cj);
-            start[j] = run + inc - cj;
-            run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-          }
+        for (int m = 0; m < RPT / 2; m++) {  // two counts per scan, in 16-bit halves (64 * 255 < 65536)
+          const uint32_t b0 = (cw[m / 2] >> (16 * (m & 1))) & 0xffu, b1 = (cw[m / 2] >> (16 * (m & 1) + 8)) & 0xffu;
+          const uint32_t inc = wave_scan_u32(b0 | (b1 << 16));
+          const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+          start[2 * m] = run + (inc & 0xffffu) - b0;
+          run += tot & 0xffffu;
+          start[2 * m + 1] = run + (inc >> 16) - b1;
+          run += tot >> 16;
         }
-        if (pace && step >= L.lag && threadIdx.x == 0)
-          pace_wait(L.pace, xcd, L.pace_steps, step - L.lag, gridDim.x);
+        if (pace && wave == 0u) {
+          // before gathering from panel `step`: the slowest workgroup of this XCD must have
+          // completed step - lag + 1 steps (all of them then sit within `lag` panels).  The
+          // board was loaded one step ago -- that load's latency ran beside the step's work --
+          // and only a minimum still short then sends this wave polling (bounded).
+          if (step >= L.lag) {
+            const uint32_t need = step + 1u - L.lag;
+            uint32_t m = have_seen ? board_min(seen) : 0u;
+            if (m < need) {
+              dbg_waits++;
+              for (int it = 0; it < 8192 && m < need; it++) {
+                __builtin_amdgcn_s_sleep(4);
+                m = board_min(board_load(board, lane));
+                dbg_spins++;
+              }
+            }
+          }
+          seen = board_load(board, lane);
+          have_seen = true;
+        }
         for (uint32_t lo = e0; lo < e1;) {
-          const uint32_t b = FMT == FMT_CSR ? (lo & ~1u) : lo;
+          const uint32_t b = lo & ~1u;
           const uint32_t hi = min(e1, b + TILE);
           __syncthreads();
-          if (FMT == FMT_CSR) csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
-          else coo_stage<MODE, EPT>(C, x, ev, lo, hi, s_prod, s_col);
+          csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
           __syncthreads();
+#ifdef ABFT_DBG_NOPHASE2  // timing-only build: wrong results
+          if (threadIdx.x == 1023u)
+#endif
 #pragma unroll
           for (int j = 0; j < RPT; j++) {
-            const uint32_t cj = CNT16 ? (cw[j / 2] >> (16 * (j & 1))) & 0xffffu : (cw[j / 4] >> (8 * (j & 3))) & 0xffu;
+            const uint32_t cj = (cw[j / 4] >> (8 * (j & 3))) & 0xffu;
             const uint32_t a0 = max(start[j], lo), a1 = min(start[j] + cj, hi);
             if (a0 < a1) {
               double t = acc[j];
-              if (FMT == FMT_CSR) csr_row_sum<MODE>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
-              else lds_ordered_add(C, ev, s_prod, s_col, a0 - lo, a1 - lo, out0 + 64u * (uint32_t)j, lo, t);
+              csr_row_sum<MODE>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
               acc[j] = t;
             }
           }
           lo = hi;
         }
       }
-      if (pace && threadIdx.x == 0)
-        __hip_atomic_fetch_add(L.pace + PACE_HDR + xcd * L.pace_steps + step, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
+      if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;  // plain store: into this XCD's L2
     }
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + 64u * (uint32_t)j;
-      if (o < n_out) {
+      if (o < A.n_out) {
         y[o] = acc[j];
         if (fused) dsum += x[fuse.x_off + o] * acc[j];
       }
@@ -1101,67 +1170,69 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_sweep_kernel(CsrDev A, CooDev
   }
   if (fused) fused_dot_finish(dsum, fuse, blockIdx.x);
   if (pace) {
-    // the workgroup that leaves last clears the counters for the next launch
-    if (threadIdx.x == 0)
-      s_last = __hip_atomic_fetch_add(L.pace + 1u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    if (threadIdx.x == 0 && L.debug) {
+      atomicAdd(L.debug, dbg_spins);
+      atomicAdd(L.debug + 1, dbg_waits);
+      atomicAdd(L.debug + 2, 1u);
+    }
+    // the workgroup that leaves last resets the registrations and the boards for the next launch
+    if (threadIdx.x == 0) {
+      if (my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;  // done: never holds anyone back
+      s_last = __hip_atomic_fetch_add(L.pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    }
     __syncthreads();
-    if (s_last)
-      for (uint32_t i = threadIdx.x; i < PACE_HDR + 8u * L.pace_steps; i += ABFT_BLOCK)
+    if (s_last) {
+      for (uint32_t i = threadIdx.x; i < PACE_HDR; i += ABFT_BLOCK)
         __hip_atomic_store(L.pace + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t i = threadIdx.x; i < 8u * PACE_SLOTS; i += ABFT_BLOCK)
+        __hip_atomic_store(L.pace + PACE_HDR + i, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
-template <int FMT, int MODE, int RPT, bool CNT16>
-static hipError_t launch_sweep_inst(const CsrDev &A, const CooDev &C, const SweepLayout &L, const double *x, double *y,
-                                    EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1,
-                                    hipStream_t s) {
-  hipLaunchKernelGGL((spmv_sweep_kernel<FMT, MODE, RPT, CNT16>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A, C, L, x, y, ev,
+template <int MODE, int RPT>
+static hipError_t launch_sweep_inst(const CsrDev &A, const SweepLayout &L, const double *x, double *y, EventRing ev,
+                                    const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+  hipLaunchKernelGGL((spmv_sweep_kernel<MODE, RPT>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A, L, x, y, ev,
                      fuse ? *fuse : FuseOut{}, fuse != nullptr, c0, c1);
   return hipGetLastError();
 }
 
-template <int FMT, int MODE, int RPT, bool CNT16> static int sweep_occupancy_inst() {
+template <int MODE, int RPT> static int sweep_occupancy_inst() {
   int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_sweep_kernel<FMT, MODE, RPT, CNT16>, ABFT_BLOCK, 0) !=
-          hipSuccess || n < 1)
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_sweep_kernel<MODE, RPT>, ABFT_BLOCK, 0) != hipSuccess || n < 1)
     n = 1;
   return n > 8 ? 8 : n;
 }
 
-// one switch for both uses: OP(FMT, MODE, RPT, CNT16)
-#define ABFT_SWEEP_DISPATCH(OP)                                                                      \
-  do {                                                                                               \
-    const int key = (fmt == FMT_COO ? 1000 : 0) + mode * 100 + (rpt == 16 ? 10 : 0) + (cnt16 ? 1 : 0); \
-    switch (key) {                                                                                   \
-      ABFT_SWEEP_CASES(OP, FMT_CSR, 0) ABFT_SWEEP_CASES(OP, FMT_COO, 1000)                           \
-      default: break;                                                                                \
-    }                                                                                                \
-  } while (0)
-#define ABFT_SWEEP_CASES(OP, F, K)                                                          \
-  ABFT_SWEEP_MODE(OP, F, K, MODE_NONE) ABFT_SWEEP_MODE(OP, F, K, MODE_SED) ABFT_SWEEP_MODE(OP, F, K, MODE_SEC7) \
-  ABFT_SWEEP_MODE(OP, F, K, MODE_SEC8) ABFT_SWEEP_MODE(OP, F, K, MODE_SECDED)
-#define ABFT_SWEEP_MODE(OP, F, K, M)                      \
-  case K + M * 100 + 0: OP(F, M, 8, false); break;        \
-  case K + M * 100 + 1: OP(F, M, 8, true); break;         \
-  case K + M * 100 + 10: OP(F, M, 16, false); break;      \
-  case K + M * 100 + 11: OP(F, M, 16, true); break;
+// one switch for both uses: OP(MODE, RPT)
+#define ABFT_SWEEP_DISPATCH(OP)                                                                    \
+  switch (mode * 100 + rpt) {                                                                      \
+    ABFT_SWEEP_MODE(OP, MODE_NONE) ABFT_SWEEP_MODE(OP, MODE_SED) ABFT_SWEEP_MODE(OP, MODE_SEC7)    \
+    ABFT_SWEEP_MODE(OP, MODE_SEC8) ABFT_SWEEP_MODE(OP, MODE_SECDED)                                \
+    default: break;                                                                                \
+  }
+#define ABFT_SWEEP_MODE(OP, M)                 \
+  case M * 100 + 2: OP(M, 2); break;           \
+  case M * 100 + 4: OP(M, 4); break;           \
+  case M * 100 + 8: OP(M, 8); break;           \
+  case M * 100 + 16: OP(M, 16); break;
 
-hipError_t launch_spmv_sweep(int fmt, int mode, int rpt, bool cnt16, const CsrDev &A, const CooDev &C,
-                             const SweepLayout &L, const double *x, double *y, EventRing ev, const FuseOut *fuse,
-                             uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+hipError_t launch_spmv_sweep(int mode, int rpt, const CsrDev &A, const SweepLayout &L, const double *x, double *y,
+                             EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
   if (L.ngroups == 0 || c0 >= c1) return hipSuccess;
-  if (c1 > L.npanels || grid == 0 || (rpt != 8 && rpt != 16)) return hipErrorInvalidValue;
+  if (c1 > L.npanels || grid == 0) return hipErrorInvalidValue;
   hipError_t e = hipErrorInvalidValue;
-#define ABFT_OP(F, M, R, W) e = launch_sweep_inst<F, M, R, W>(A, C, L, x, y, ev, fuse, grid, c0, c1, s)
-  ABFT_SWEEP_DISPATCH(ABFT_OP);
+#define ABFT_OP(M, R) e = launch_sweep_inst<M, R>(A, L, x, y, ev, fuse, grid, c0, c1, s)
+  ABFT_SWEEP_DISPATCH(ABFT_OP)
 #undef ABFT_OP
   return e;
 }
 
-int spmv_sweep_blocks_per_cu(int fmt, int mode, int rpt, bool cnt16) {
+int spmv_sweep_blocks_per_cu(int mode, int rpt) {
   int n = 1;
-#define ABFT_OP(F, M, R, W) n = sweep_occupancy_inst<F, M, R, W>()
-  ABFT_SWEEP_DISPATCH(ABFT_OP);
+#define ABFT_OP(M, R) n = sweep_occupancy_inst<M, R>()
+  ABFT_SWEEP_DISPATCH(ABFT_OP)
 #undef ABFT_OP
   return n;
 }
@@ -1177,8 +1248,24 @@ int spmv_sweep_blocks_per_cu(int fmt, int mode, int rpt, bool cnt16) {
 // the (repaired) stored words, merged by caller's index with the queued products.
 // Stored order inside a group is the caller's order in both layouts, so the merge is a
 // two-way merge.  A fused vec.result product is corrected through partial 0.
+// where output c's own elements sit: the one group (streaming layout), or its slice of
+// segment (group, panel rg) in the panel layout
+struct FixLayout {
+  int kind;  // 0 streaming, 1 panels
+  CsrPanels P;
+};
+__device__ __forceinline__ void fixup_range(const CooDev &A, const FixLayout &F, uint32_t c, uint32_t rg, uint32_t &lo,
+                                            uint32_t &hi) {
+  if (F.kind == 0) { lo = A.grp_ptr[c]; hi = A.grp_ptr[c + 1]; return; }
+  const uint32_t seg = (c / ABFT_PANEL_ROWS) * F.P.npanels + rg;
+  const uint32_t e0 = F.P.seg_base[seg];
+  const uint16_t *ptr = F.P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+  lo = e0 + ptr[c % ABFT_PANEL_ROWS];
+  hi = e0 + ptr[c % ABFT_PANEL_ROWS + 1];
+}
+
 template <int MODE>
-__global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, CsrPanels P, bool panels,
+__global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, FixLayout F,
                                                                const double *__restrict__ x, double *__restrict__ y,
                                                                FuseOut fuse, bool fused) {
   __shared__ double s_p[ABFT_BLOCK];
@@ -1208,18 +1295,10 @@ __global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, CsrPane
     while (q1 < n && srt[q1].col == c) q1++;
     double sum = 0.0;   // thread 0 only
     uint32_t qi = q;    // thread 0 only
-    const uint32_t nranges = panels ? P.npanels : 1u;
+    const uint32_t nranges = F.kind == 0 ? 1u : F.P.npanels;
     for (uint32_t rg = 0; rg < nranges; rg++) {
       uint32_t lo, hi;
-      if (panels) {
-        const uint32_t seg = (c / ABFT_PANEL_ROWS) * P.npanels + rg;
-        const uint32_t e0 = P.seg_base[seg];
-        const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
-        lo = e0 + ptr[c % ABFT_PANEL_ROWS];
-        hi = e0 + ptr[c % ABFT_PANEL_ROWS + 1];
-      } else {
-        lo = A.grp_ptr[c]; hi = A.grp_ptr[c + 1];
-      }
+      fixup_range(A, F, c, rg, lo, hi);
       for (uint32_t base = lo; base < hi; base += ABFT_BLOCK) {
         const uint32_t j = base + threadIdx.x;
         if (j < hi) {
@@ -1258,13 +1337,15 @@ __global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, CsrPane
   if (threadIdx.x == 0) __hip_atomic_store(A.moved.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y,
-                            EventRing ev, const FuseOut *fuse, hipStream_t s) {
+hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, EventRing ev,
+                            const FuseOut *fuse, hipStream_t s) {
   (void)ev;
   if (!A.moved.buf || A.nnz == 0) return hipSuccess;
-  const CsrPanels pp = P ? *P : CsrPanels{};
+  FixLayout F{};
+  F.kind = P ? 1 : 0;
+  if (P) F.P = *P;
   const FuseOut f = fuse ? *fuse : FuseOut{};
-#define ABFT_FIX(M) hipLaunchKernelGGL(coo_fixup_kernel<M>, dim3(1), dim3(ABFT_BLOCK), 0, s, A, pp, P != nullptr, x, y, f, fuse != nullptr)
+#define ABFT_FIX(M) hipLaunchKernelGGL(coo_fixup_kernel<M>, dim3(1), dim3(ABFT_BLOCK), 0, s, A, F, x, y, f, fuse != nullptr)
   if (mode >= MODE_SED) ABFT_FIX(MODE_SED); else ABFT_FIX(MODE_NONE);
 #undef ABFT_FIX
   return hipGetLastError();

@@ -120,7 +120,7 @@ int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int mode,
 /* reference CSR/CPUContext.cpp:46-52 */
 int abft_hip_matrix_destroy(abft_hip_matrix *mat);
 /* How the matrix is stored and run (measurement only): *layout = 0 streaming row blocks,
- * 1 column panels; *launches_per_spmv = kernel launches one abft_hip_spmv enqueues (what
+ * 1 column panels (chunked launches), 2 sweep (one persistent launch); *launches_per_spmv = kernel launches one abft_hip_spmv enqueues (what
  * ABFT_K_SPMV's bracket spans), without the fold of a fused product. */
 int abft_hip_matrix_info(abft_hip_matrix *mat, int *layout, int *launches_per_spmv);
 

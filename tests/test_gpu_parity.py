@@ -443,6 +443,50 @@ def test_fused_dot_is_transparent(amd, fmt):
 
 
 @pytest.mark.parametrize("fmt", FMTS)
+@pytest.mark.parametrize("width,rpt,lag", [(16, 8, 2), (16, 16, 0), (257, 2, 1), (100000, 4, 3), (64, 8, 2)])
+def test_sweep_layout_forced_on_small_matrices(amd, fmt, width, rpt, lag, monkeypatch):
+    """The sweep layout (CSR: one persistent launch over (row group, panel) segments, running
+    sums in registers, paced per XCD) is normally chosen only for large scattered matrices
+    (full size: test_gpu_fullsize); force it here with tiny panels, every group size and
+    several pacing lags through the same checks as the streaming layout: stored elements in
+    the caller's order, SpMV bit-identical, flips reported with the caller's index and
+    repaired, fused dot.  COO, and CSR matrices with more than 255 elements of a row in one
+    panel, take the panel layout instead (same checks)."""
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep")
+    monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", str(width))
+    monkeypatch.setenv("ABFT_HIP_SWEEP_RPT", str(rpt))
+    monkeypatch.setenv("ABFT_HIP_SWEEP_LAG", str(lag))
+    for mat in ("ragged", "rnd300", "lap40", "one", "tail_empty"):
+        cols, rows, vals, n = MATS[mat]()
+        x = rhs(n, 11) - 0.5
+        for mode in ("none", "sec8", "secded"):
+            o = OracleMatrix(fmt, mode, cols, rows, vals, n)
+            h = Hip(amd, fmt, mode, cols, rows, vals, n)
+            try:
+                layout = h.ctx.matrix_info(h.A)[0]
+                assert layout == ("sweep" if fmt == CSR and (mat != "ragged" or width <= 64) else "panels"), (mat, layout)
+                assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+                assert bits_equal(h.spmv(x), o.spmv(x))
+                assert h.take_events() == ([], False)
+                if mode != "none" and len(vals) > 2:
+                    idx = [0, len(vals) // 2, len(vals) - 1]
+                    for k, i in enumerate(idx):
+                        o.inject(i, [7 + 30 * k])
+                        h.ctx.inject_at(h.A, i, [7 + 30 * k])
+                    assert bits_equal(h.spmv(x), o.spmv(x))
+                    assert h.take_events() == o.events()
+                    assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+                for _ in range(2):  # again (pacing counters were reset by the last workgroup), with the fused dot
+                    h.ctx.spmv(h.A, h.vx, h.vy)
+                    d = h.ctx.dot(h.vx, h.vy)
+                    y = h.ctx.download(h.vy)
+                    assert bits_equal(y, o.spmv(x))
+                    assert abs(d - ora_dot(x, y)) <= 1e-13 * float(np.abs(x * y).sum()) + 1e-300
+            finally:
+                h.close()
+
+
+@pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("width,chunk", [(16, 0), (16, 3), (257, 1), (100000, 2)])
 def test_panel_layout_forced_on_small_matrices(amd, fmt, width, chunk, monkeypatch):
     """The panel (column-blocked) layout is normally chosen only for large
@@ -480,7 +524,7 @@ def test_panel_layout_forced_on_small_matrices(amd, fmt, width, chunk, monkeypat
                 h.close()
 
 
-@pytest.mark.parametrize("layout", ["stream", "panels"])
+@pytest.mark.parametrize("layout", ["stream", "panels", "sweep"])
 @pytest.mark.parametrize("mode", ["none", "constraints", "sed", "sec7", "sec8"])
 def test_coo_silently_corrupted_column_scatters_like_reference(amd, mode, layout, monkeypatch):
     """cg-coo with a column field corrupted where no check sees it (none / constraints:

@@ -66,7 +66,9 @@ def one_case(seed):
     nnz = len(vals)
     fmt = CSR if rng.random() < 0.6 else COO
     mode = str(rng.choice(MODES))
-    layout = str(rng.choice(["stream", "panels", "auto"]))
+    layout = str(rng.choice(["stream", "panels", "sweep", "sweep", "auto"]))
+    os.environ["ABFT_HIP_SWEEP_RPT"] = str(int(rng.choice([8, 16])))
+    os.environ["ABFT_HIP_SWEEP_LAG"] = str(int(rng.choice([0, 1, 2, 3])))
     os.environ["ABFT_HIP_LAYOUT"] = layout
     os.environ["ABFT_HIP_PANEL_WIDTH"] = str(int(rng.choice([16, 100, 257, 4096])))
     os.environ["ABFT_HIP_PANEL_CHUNK"] = str(int(rng.choice([0, 1, 2, 3])))

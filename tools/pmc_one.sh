@@ -1,12 +1,15 @@
 #!/bin/bash
-# usage: tools/pmc_one.sh <tag> "<bench args>" : FETCH_SIZE + TCC hit/miss of every kernel, summarized
+# PMC passes (separate runs, as the guide prescribes) for one bench.py workload:
+#   tools/pmc_one.sh NAME ENV... -- BENCH_ARGS...   -> gpurun_out/r2/pmc_NAME_*.json
 export TMPDIR=/tmp
-O=gpurun_out/pmc_$1
-rm -rf $O; mkdir -p $O
-rocprofv3 --pmc FETCH_SIZE -f csv -d $O/f -- python3 bench.py --cpu-iters 0 --steps 4 --warmup 1 --no-profile $2 > /dev/null 2> $O/f.err
-python3 profiles/summarize.py pmc $O/f $O/fetch.json | grep -i spmv
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -f csv -d $O/t -- python3 bench.py --cpu-iters 0 --steps 4 --warmup 1 --no-profile $2 > /dev/null 2> $O/t.err
-python3 profiles/summarize.py pmc $O/t $O/tcc.json | grep -i spmv
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD -f csv -d $O/s -- python3 bench.py --cpu-iters 0 --steps 4 --warmup 1 --no-profile $2 > /dev/null 2> $O/s.err
-python3 profiles/summarize.py pmc $O/s $O/sq.json | grep -i spmv
-rm -rf $O/f $O/t $O/s
+O=gpurun_out/r2; mkdir -p $O
+name=$1; shift
+envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+for e in "${envs[@]}"; do export "$e"; done
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  n=$(echo $c | cut -d' ' -f1 | tr A-Z a-z)
+  rm -rf $O/raw_$name_$n
+  rocprofv3 --pmc $c -f csv -d $O/raw_${name}_$n -- python3 bench.py --cpu-iters 0 --no-probe --no-extras --no-profile --steps 5 --warmup 1 "$@" > /dev/null 2> $O/pmc_${name}_$n.err
+  python3 profiles/summarize.py pmc $O/raw_${name}_$n $O/pmc_${name}_$n.json | grep -i -E "spmv|sweep|fixup"
+  rm -rf $O/raw_${name}_$n
+done

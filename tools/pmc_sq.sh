@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
            "MemUnitStalled MeanOccupancyPerCU" ; do
   i=$((i+1))
-  rocprofv3 --pmc $set -f csv -d $O/p$i -- python3 bench.py --cpu-iters 0 --steps 4 --warmup 1 --no-profile $2 > /dev/null 2> $O/p$i.err
+  rocprofv3 --pmc $set -f csv -d $O/p$i -- python3 bench.py --cpu-iters 0 --steps 4 --warmup 1 --no-profile --no-probe --no-extras $2 > /dev/null 2> $O/p$i.err
   python3 profiles/summarize.py pmc $O/p$i $O/p$i.json | grep -i "spmv" 
   rm -rf $O/p$i
 done
