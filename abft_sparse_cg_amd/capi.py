@@ -53,6 +53,8 @@ SIGNATURES = {
     "abft_hip_matrix_create_coo": (C.c_int, [vp, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int, vpp]),
     "abft_hip_matrix_create_shard": (C.c_int, [vp, C.c_int, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int,
                                                C.c_int, C.c_uint32, vpp]),
+    "abft_hip_matrix_create_shard_indexed": (C.c_int, [vp, C.c_int, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int,
+                                                       C.c_int, u32p, vpp]),
     "abft_hip_matrix_destroy": (C.c_int, [vp]),
     "abft_hip_matrix_info": (C.c_int, [vp, i32p, i32p]),
     "abft_hip_matrix_read_csr": (C.c_int, [vp, vp, vp, vp]),
@@ -79,6 +81,11 @@ SIGNATURES = {
     "abft_hip_spmv_dot_part_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int]),
     "abft_hip_calc_xr_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "abft_hip_calc_p_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp]),
+    "abft_hip_write_pair": (C.c_int, [vp, vp, C.c_double, C.c_double]),
+    "abft_hip_graph_begin": (C.c_int, [vp]),
+    "abft_hip_graph_end": (C.c_int, [vp, vpp]),
+    "abft_hip_graph_launch": (C.c_int, [vp]),
+    "abft_hip_graph_destroy": (C.c_int, [vp]),
     "abft_hip_drain_events": (C.c_int, [vp, C.POINTER(Event), C.c_int, i32p, i32p]),
     "abft_hip_event_capacity": (C.c_int, []),
     "abft_hip_pending_events": (C.c_int, [vp]),

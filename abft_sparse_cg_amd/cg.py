@@ -1,15 +1,13 @@
-"""cg.py -- the reference driver's command line (cg.cpp:38-309) for the hip target,
-runnable on one GPU or, under torch.distributed.run, row-partitioned over N GPUs:
+"""cg.py -- the reference driver's command line (cg.cpp:38-309) for the hip target on one
+GPU, through the ctypes mirror of the plugin interface (context.HIPContext):
 
-    python -m abft_sparse_cg_amd.cg -s laplace5:3162,3162 -m secded -i 200 -c 0
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        -m abft_sparse_cg_amd.cg --format csr -s random:4194304,24,1 -m secded
+    python -m abft_sparse_cg_amd.cg -t hip -s laplace5:3162,3162 -m secded -i 200 -c 0
 
-Same flags, defaults and stdout as cg-csr / cg-coo (rank 0 prints); additions:
---format csr|coo (the reference picks the format by executable), -s/--synthetic,
---seed, --flip-at INDEX:BIT[,BIT...], -q/--quiet.  The single-process path drives
-HIPContext call for call like the C++ driver; the multi-process path drives
-distributed.ShardedCG (CSR only).
+Same flags, defaults and stdout as cg-csr / cg-coo; additions: --format csr|coo (the
+reference picks the format by executable), -s/--synthetic, --seed, --flip-at
+INDEX:BIT[,BIT...], -q/--quiet.  It drives HIPContext call for call like the C++ driver.
+Several GPUs: the C++ executables (host/cg-csr, host/cg-coo under host/mgpu-run or
+torch.distributed.run --no-python) are the one multi-process implementation.
 """
 import ctypes
 import math
@@ -180,9 +178,9 @@ def main(argv=None):
     if o["target"] != "hip" or o["mode"] not in list(MODES) + ["sec"]:
         sys.stderr.write("\nNo implementation found for %s-%s\n\n" % (o["target"], o["mode"]))
         return 1
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or os.environ.get("ABFT_CG_SHARDED") == "1":  # the latter: sharded path with one rank (tests)
-        return run_sharded(o, world)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        fail("several ranks: run host/cg-csr or host/cg-coo under this launcher (--no-python); "
+             "this Python driver is single-GPU")
     return run_single(o)
 
 
@@ -250,65 +248,6 @@ def run_single(o):
     ctx.destroy_matrix(A)
     ctx.close()
     return 0
-
-
-def run_sharded(o, world):
-    import torch
-    import torch.distributed as dist
-
-    from . import generators
-    from .distributed import HipEngine, ShardedCG
-    if o["fmt"] != "csr":
-        fail("the row-partitioned solver shards CSR; run --format coo on one GPU")
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if rank != 0:
-        sys.stdout = open(os.devnull, "w")  # rank 0 speaks for the job
-    if o["synthetic"]:
-        n = generators.dim(o["synthetic"])
-        bounds = generators.partition(o["synthetic"], world)
-        cols, rows, vals, _, block = load_matrix(o, bounds[rank], bounds[rank + 1])
-    else:
-        cols, rows, vals, n, block = load_matrix(o)
-        cum = np.cumsum(np.bincount(rows, minlength=n))
-        bounds = [0] + [int(np.searchsorted(cum, cum[-1] * g / world)) for g in range(1, world)] + [n]
-        m = (rows >= bounds[rank]) & (rows < bounds[rank + 1])
-        cols, rows, vals = cols[m], rows[m], vals[m]
-    counts = [None] * world
-    dist.all_gather_object(counts, len(vals))
-    nnz, before = sum(counts), sum(counts[:rank])
-    eng = HipEngine(o["mode"], "csr", device=local)
-    cg = ShardedCG(eng, cols, rows, vals, bounds, before, o["mode"])
-    header(o, n, block, nnz)
-    cg.set_rhs(generators.reference_rhs(n)[bounds[rank]:bounds[rank + 1]])
-    flip = [draw_flips(o, nnz)]
-    dist.broadcast_object_list(flip, src=0)  # one set of draws for the job
-    if flip[0]:
-        idx, bits = flip[0]
-        for bit in bits:
-            print("*** flipping bit %d at index %d ***" % (bit, idx))
-        if before <= idx < before + counts[rank]:
-            eng.inject(cg.A, idx - before, bits)
-    t0 = time.perf_counter()
-    code = 0
-    try:
-        itr, rr = cg.solve(o["max_itrs"], o["conv"], None if o["quiet"] else
-                           (lambda i, r: print("iteration %5u :  rr = %12.4f" % (i, r))))
-        ms = (time.perf_counter() - t0) * 1e3
-        print("\nran for %u iterations" % itr)
-        print("\ntime taken = %7.2f ms\n" % ms)
-        tot, mx = cg.residual_check()
-        print("total error = %f" % tot)
-        print("max error   = %f" % mx)
-        print()
-    except SystemExit as e:
-        code = int(e.code or 0)
-    sys.stdout.flush()
-    eng.close()
-    dist.destroy_process_group()
-    return code
 
 
 if __name__ == "__main__":

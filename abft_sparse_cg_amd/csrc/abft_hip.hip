@@ -795,6 +795,24 @@ extern "C" int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int m
   return create_any(ctx, format, mode, columns, rows, values, n_out, n_in, nnz, index_base, mat);
 }
 
+extern "C" int abft_hip_matrix_create_shard_indexed(abft_hip_ctx *ctx, int format, int mode,
+                                                    const uint32_t *columns, const uint32_t *rows,
+                                                    const double *values, int n_out, int n_in, int nnz,
+                                                    const uint32_t *global_index, abft_hip_matrix **mat) {
+  if (int rc = create_any(ctx, format, mode, columns, rows, values, n_out, n_in, nnz, 0, mat)) return rc;
+  if (!global_index || nnz == 0) return ABFT_OK;
+  abft_hip_matrix *m = *mat;
+  uint32_t *d = nullptr;
+  if (int rc = dev_upload(m, &d, global_index, (size_t)nnz, (size_t)nnz)) {
+    matrix_free(m);
+    *mat = nullptr;
+    return rc;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // the caller's array
+  if (format == ABFT_FMT_CSR) m->csr.gidx = d; else m->coo.gidx = d;
+  return ABFT_OK;
+}
+
 extern "C" int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, int row_hi) {
   if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
   const int n_out = mat->fmt == ABFT_FMT_CSR ? (int)mat->csr.n_out : (int)mat->coo.n_out;
@@ -1138,6 +1156,16 @@ extern "C" int abft_hip_read_pair(abft_hip_ctx *ctx, const double *dev_pair, dou
   return ABFT_OK;
 }
 
+// the way back (host-staged collectives: several ranks on one GPU in the tests)
+extern "C" int abft_hip_write_pair(abft_hip_ctx *ctx, double *dev_pair, double value, double events) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!dev_pair) return set_err(ABFT_ERR_INVALID, "null argument");
+  const double v[2] = {value, events};
+  HIPCHK(hipMemcpyAsync(dev_pair, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // `v` is on the stack
+  return ABFT_OK;
+}
+
 // ---- device-scalar forms: alpha and beta never leave the GPU -------------------
 
 extern "C" int abft_hip_calc_xr_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
@@ -1259,6 +1287,68 @@ extern "C" int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *ma
                                           abft_hip_vector *result, int vec_offset, double *dev_result, int part) {
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
   return spmv_common(ctx, mat, vec, result, vec_offset, dev_result, part);
+}
+
+// ------------------------------------------------------------- graph replay --
+
+// A captured sequence of asynchronous calls on the context's stream (and of whatever else
+// the caller enqueues there meanwhile, e.g. RCCL collectives), replayed with one launch:
+// the fixed-iteration CG loop keeps its scalars on the device, so an iteration is
+// enqueue-only and the host cost of ~8 launches per iteration is what is left to remove.
+struct abft_hip_graph {
+  abft_hip_ctx *ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int abft_hip_graph_begin(abft_hip_ctx *ctx) {
+  if (int rc = bind(ctx)) return rc;
+  if (ctx->prof) return set_err(ABFT_ERR_INVALID, "graph capture with kernel brackets enabled (abft_hip_profile_enable)");
+  HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_graph_end(abft_hip_ctx *ctx, abft_hip_graph **out) {
+  if (!ctx || !out) return set_err(ABFT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (ctx->defer.active) {  // the captured sequence must leave nothing pending on the host side
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture(ctx->stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+    ctx->defer.active = false;
+    return set_err(ABFT_ERR_INVALID, "captured sequence ends with a deferred x update pending (calc_xr without its calc_p)");
+  }
+  hipGraph_t g = nullptr;
+  HIPCHK(hipStreamEndCapture(ctx->stream, &g));
+  abft_hip_graph *h = new (std::nothrow) abft_hip_graph();
+  if (!h) { (void)hipGraphDestroy(g); return set_err(ABFT_ERR_NOMEM, "graph handle"); }
+  h->ctx = ctx; h->graph = g;
+  hipError_t e = hipGraphInstantiate(&h->exec, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    delete h;
+    return set_err(ABFT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  *out = h;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_graph_launch(abft_hip_graph *g) {
+  if (!g) return set_err(ABFT_ERR_INVALID, "null graph");
+  if (int rc = bind(g->ctx)) return rc;
+  g->ctx->fused.valid = false;
+  HIPCHK(hipGraphLaunch(g->exec, g->ctx->stream));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_graph_destroy(abft_hip_graph *g) {
+  if (!g) return ABFT_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+  return ABFT_OK;
 }
 
 // ------------------------------------------------------------------- events --

@@ -26,6 +26,7 @@ struct CsrDev {
   // (row group, column panel); these map storage position <-> caller's index.
   const uint32_t *orig_index;   // cold path: event messages carry the caller's element index
   const uint32_t *pos_of_orig;  // inject
+  const uint32_t *gidx;         // shards whose elements are not one run of the caller's: global index of local element k
 };
 
 // Panel ("column-blocked") layout for matrices whose columns are scattered over
@@ -99,6 +100,7 @@ struct CooDev {
   const uint32_t *pos_of_orig;  // caller's element index -> stored position
   uint32_t nblk, n_out, n_in, nnz, index_base;
   MovedList moved;
+  const uint32_t *gidx;         // column-block shards: global (caller's) index of local element k; else index_base + k
 };
 
 #define ABFT_COLMASK_HOST 0x00FFFFFFu

@@ -121,6 +121,16 @@ __device__ __noinline__ EccWords<FMT> ecc_cold(EccWords<FMT> e, uint32_t gidx, E
   return e;
 }
 
+// the element index an event line carries: the caller's, global across shards
+__device__ __forceinline__ uint32_t event_index(const CsrDev &A, uint32_t i) {
+  const uint32_t o = A.orig_index ? A.orig_index[i] : i;
+  return A.gidx ? A.gidx[o] : A.index_base + o;
+}
+__device__ __forceinline__ uint32_t event_index(const CooDev &A, uint32_t j) {
+  const uint32_t o = A.orig_index[j];
+  return A.gidx ? A.gidx[o] : A.index_base + o;
+}
+
 // Hot-path test: non-zero iff the element needs the cold path.
 template <int FMT, int MODE>
 __device__ __forceinline__ uint32_t ecc_suspect(const uint32_t *w) {
@@ -314,7 +324,7 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
       if (__builtin_expect(valid && ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
         EccWords<FMT_CSR> e;
         e.w[0] = w[0]; e.w[1] = w[1]; e.w[2] = w[2]; e.rc = 0;
-        e = ecc_cold<FMT_CSR, MODE>(e, A.index_base + (A.orig_index ? A.orig_index[i] : i), ev);
+        e = ecc_cold<FMT_CSR, MODE>(e, event_index(A, i), ev);
         w[0] = e.w[0]; w[1] = e.w[1]; w[2] = e.w[2];
         if (e.rc > 0) {  // reference CSR/CPUContext.cpp:275-276, 333-334, 389-390
           A.vals[i] = as_double(w[0], w[1]);
@@ -688,7 +698,7 @@ __device__ __forceinline__ void coo_consume(const CooDev &A, const double *__res
     if (MODE == MODE_CONSTRAINTS) {
       if (valid) {  // per-element structural checks: a cold, gather-heavy mode by nature
         const uint32_t i = A.orig_index[j];
-        const uint32_t gi = A.index_base + i;
+        const uint32_t gi = event_index(A, j);
         if (w[1] >= A.n_in) { push_event(ev, ABFT_EV_ROW_SIZE, gi, 0, FMT_COO); valid = false; }
         else if (w[0] >= A.n_out) { push_event(ev, ABFT_EV_COL_SIZE, gi, 0, FMT_COO); valid = false; }
         else if (i + 1u < A.nnz) {
@@ -701,7 +711,7 @@ __device__ __forceinline__ void coo_consume(const CooDev &A, const double *__res
       if (__builtin_expect(valid && ecc_suspect<FMT_COO, MODE>(w) != 0, 0)) {
         EccWords<FMT_COO> ce;
         ce.w[0] = w[0]; ce.w[1] = w[1]; ce.w[2] = w[2]; ce.w[3] = w[3]; ce.rc = 0;
-        ce = ecc_cold<FMT_COO, MODE>(ce, A.index_base + A.orig_index[j], ev);
+        ce = ecc_cold<FMT_COO, MODE>(ce, event_index(A, j), ev);
         w[0] = ce.w[0]; w[1] = ce.w[1]; w[2] = ce.w[2]; w[3] = ce.w[3];
         if (ce.rc > 0) A.elems[j] = make_uint4(w[0], w[1], w[2], w[3]);  // COO/CPUContext.cpp:255, 310, 364
         else valid = false;

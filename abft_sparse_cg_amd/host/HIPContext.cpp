@@ -6,23 +6,23 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <chrono>
+
 #include "comm.h"
+#include "partition.h"
 
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
-    r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL)
+    r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
+    fixed_scal_(NULL), fixed_scal_dev_(NULL)
 {
+  fixed_graph_[0] = fixed_graph_[1] = NULL;
   int device = comm_ ? comm_->local_rank() : 0;
   if (const char *env = getenv("ABFT_HIP_DEVICE"))
     device = atoi(env);
   check(abft_hip_init(device, &ctx_), "abft_hip_init");
   if (comm_)
   {
-    if (format_ != ABFT_FMT_CSR)
-    {
-      fprintf(stderr, "hip backend: the row-partitioned target shards CSR (cg-csr); cg-coo runs on one GPU\n");
-      exit(2);
-    }
     comm_->enable_device_collectives(device);
     check(abft_hip_vector_create(ctx_, 2, &pair_), "abft_hip_vector_create");
     pair_dev_ = (double *)abft_hip_vector_device_ptr(pair_);
@@ -37,6 +37,11 @@ HIPContextBase::~HIPContextBase()
   if (ctx_)
   {
     report_events(true);
+    for (int k = 0; k < 2; k++)
+      if (fixed_graph_[k])
+        abft_hip_graph_destroy(fixed_graph_[k]);
+    if (fixed_scal_)
+      abft_hip_vector_destroy(fixed_scal_);
     if (pair_)
       abft_hip_vector_destroy(pair_);
     abft_hip_shutdown(ctx_);
@@ -149,97 +154,100 @@ cg_matrix* HIPContextBase::create_matrix(const uint32_t *columns, const uint32_t
     return M;
   }
 
-  // ---- row blocks of (nearly) equal non-zero count; every rank computes the same cut ----
-  const int G = comm_->size(), me = comm_->rank();
+  // ---- blocks of outputs (CSR rows / COO columns) of (nearly) equal non-zero count; every rank
+  // ---- computes the same cut (partition.h) ----
+  const int G = comm_->size();
   if (N < G)
   {
     fprintf(stderr, "hip backend: %d ranks for a matrix of %d rows\n", G, N);
     exit(2);
   }
-  bounds_.assign(G + 1, 0);
-  bounds_[G] = N;
-  for (int g = 1; g < G; g++)
+  std::vector<int> bounds;
+  if (format_ == ABFT_FMT_CSR)
+    plan_bounds_sorted(rows, nnz, N, G, bounds);
+  else
   {
-    int row = nnz ? (int)rows[(size_t)((unsigned long long)nnz * g / G)] : (int)((long long)N * g / G);
-    row = std::max(row, bounds_[g - 1] + 1);   // at least one row each ...
-    row = std::min(row, N - (G - g));          // ... and room for the ranks behind
-    bounds_[g] = row;
+    std::vector<long long> per((size_t)N, 0);
+    for (int i = 0; i < nnz; i++)
+      if (columns[i] < (uint32_t)N) per[columns[i]]++;
+    plan_bounds_counts(per, N, G, bounds);
   }
-  slot_ = 0;
-  for (int g = 0; g < G; g++)
-    slot_ = std::max(slot_, bounds_[g + 1] - bounds_[g]);
-  n_pad_ = slot_ * G;
-  r0_ = bounds_[me];
-  n_loc_ = bounds_[me + 1] - r0_;
-  const uint32_t *lo = std::lower_bound(rows, rows + nnz, (uint32_t)r0_);
-  const uint32_t *hi = std::lower_bound(rows, rows + nnz, (uint32_t)(r0_ + n_loc_));
-  const size_t e0 = lo - rows, cnt = hi - lo;
-  M->nnz_before = (unsigned)e0;
+  ShardPlan plan;
+  plan_shard(format_, columns, rows, values, 0, (size_t)nnz, N, bounds, comm_->rank(), plan);
+  adopt_plan(M, plan);
+  return M;
+}
+
+// The driver generated only this rank's row block (synthetic inputs: every rank would otherwise
+// build the whole matrix, 8 x 1.7 GB of host memory and 8 x the generator time for config 4).
+cg_matrix* HIPContextBase::create_matrix_rows(const uint32_t *columns, const uint32_t *rows, const double *values,
+                                              int N, long long nnz_total, const long long *row_bounds,
+                                              long long elem0, long long count)
+{
+  if (!comm_ || format_ != ABFT_FMT_CSR)
+    return NULL;
+  cg_matrix *M = new cg_matrix;
+  M->N = N;
+  M->nnz = (unsigned)nnz_total;
+  M->handle = NULL;
+  std::vector<int> bounds((size_t)comm_->size() + 1);
+  for (int g = 0; g <= comm_->size(); g++) bounds[g] = (int)row_bounds[g];
+  ShardPlan plan;
+  plan_shard(ABFT_FMT_CSR, columns, rows, values, (size_t)elem0, (size_t)count, N, bounds, comm_->rank(), plan);
+  adopt_plan(M, plan);
+  return M;
+}
+
+// shard geometry -> device matrix, exchange pattern, overlap decision
+void HIPContextBase::adopt_plan(cg_matrix *M, const ShardPlan &plan)
+{
+  const int G = comm_->size(), me = comm_->rank();
+  bounds_ = plan.bounds;
+  slot_ = plan.slot; n_pad_ = plan.n_pad; r0_ = plan.out0; n_loc_ = plan.n_loc;
+  const size_t cnt = plan.lout.size();
+  M->nnz_before = (unsigned)plan.first;
   M->nnz_local = (unsigned)cnt;
-  // local rows; columns re-based to the slot-padded gathered vector (slot g at [g*slot, ...))
-  // ... noting which window of each peer's slot this rank reads, and which rows read a peer at all
-  std::vector<uint32_t> lrows(cnt ? cnt : 1), pcols(cnt ? cnt : 1);
-  std::vector<int> need(2 * (size_t)G, 0);  // per peer: [lo, hi) inside its slot
-  std::vector<char> remote((size_t)n_loc_, 0);
-  for (int g = 0; g < G; g++) need[2 * g] = slot_;
-  for (size_t i = 0; i < cnt; i++)
-  {
-    lrows[i] = rows[e0 + i] - (uint32_t)r0_;
-    const uint32_t c = columns[e0 + i];
-    if (c >= (uint32_t)N)
-    {
-      pcols[i] = (uint32_t)n_pad_;  // out of range stays out of range (the kernel reads 0.0, as on one GPU)
-      continue;
-    }
-    const int owner = (int)(std::upper_bound(bounds_.begin(), bounds_.end(), (int)c) - bounds_.begin()) - 1;
-    const int off = (int)c - bounds_[owner];
-    pcols[i] = (uint32_t)(owner * slot_ + off);
-    if (owner != me)
-    {
-      need[2 * owner] = std::min(need[2 * owner], off);
-      need[2 * owner + 1] = std::max(need[2 * owner + 1], off + 1);
-      remote[lrows[i]] = 1;
-    }
-  }
-  for (int g = 0; g < G; g++)
-    if (need[2 * g + 1] <= need[2 * g]) need[2 * g] = need[2 * g + 1] = 0;
+  M->global_index = plan.global_index;
   all_need_.assign(2 * (size_t)G * G, 0);
-  comm_->allgather(need.data(), sizeof(int) * need.size(), all_need_.data());
+  comm_->allgather(plan.need.data(), sizeof(int) * plan.need.size(), all_need_.data());
   long long moved = 0;
   for (size_t k = 0; k < all_need_.size(); k += 2) moved += all_need_[k + 1] - all_need_[k];
   // windows pay when they move well under half of what the all-gather moves (banded matrices: the halo)
-  use_windows_ = moved * 2 < (long long)N * (G - 1);
-  check(abft_hip_matrix_create_shard(ctx_, format_, mode_, pcols.data(), lrows.data(), values + e0, n_loc_,
-                                     n_pad_, (int)cnt, (uint32_t)e0, &M->handle),
-        "abft_hip_matrix_create_shard");
-  // the longest run of rows that read only this rank's own slot can be multiplied while
+  use_windows_ = moved * 2 < (long long)M->N * (G - 1);
+  static const uint32_t none32 = 0;
+  static const double none64 = 0.0;
+  const uint32_t *lout = cnt ? plan.lout.data() : &none32, *pin = cnt ? plan.pin.data() : &none32;
+  const double *vals = cnt ? plan.vals.data() : &none64;
+  // CSR: columns = padded gather index, rows = local output; COO: columns = local output, rows = padded gather index
+  const uint32_t *c = format_ == ABFT_FMT_CSR ? pin : lout, *r = format_ == ABFT_FMT_CSR ? lout : pin;
+  if (plan.global_index.empty())
+    check(abft_hip_matrix_create_shard(ctx_, format_, mode_, c, r, vals, n_loc_, n_pad_, (int)cnt,
+                                       (uint32_t)plan.first, &M->handle),
+          "abft_hip_matrix_create_shard");
+  else
+    check(abft_hip_matrix_create_shard_indexed(ctx_, format_, mode_, c, r, vals, n_loc_, n_pad_, (int)cnt,
+                                               plan.global_index.data(), &M->handle),
+          "abft_hip_matrix_create_shard_indexed");
+  // the longest run of outputs that read only this rank's own slot can be multiplied while
   // the exchange is in flight (row sums are never split: results stay bit-identical)
-  int best_lo = 0, best_hi = 0, run = 0;
-  for (int r = 0; r <= n_loc_; r++)
-  {
-    if (r < n_loc_ && !remote[r]) { run++; continue; }
-    if (run > best_hi - best_lo) { best_lo = r - run; best_hi = r; }
-    run = 0;
-  }
-  const bool interior = best_hi - best_lo >= std::max(n_loc_ / 4, 1);
+  const bool interior = plan.interior_hi > plan.interior_lo;
   if (interior)
-    check(abft_hip_matrix_set_interior(M->handle, best_lo, best_hi), "abft_hip_matrix_set_interior");
+    check(abft_hip_matrix_set_interior(M->handle, plan.interior_lo, plan.interior_hi), "abft_hip_matrix_set_interior");
   // ... which is worth its two stream hand-offs (~20 us) only for a long exchange; a halo of a few
   // KB goes on the compute stream in front of a single SpMV launch (ABFT_CG_OVERLAP_BYTES decides)
   long long incoming = 0;
   if (use_windows_)
-    for (int g = 0; g < G; g++) incoming += need[2 * g + 1] - need[2 * g];
+    for (int g = 0; g < G; g++) incoming += plan.need[2 * g + 1] - plan.need[2 * g];
   else
     incoming = (long long)(G - 1) * slot_;
   long long least = 2ll << 20;
   if (const char *env = getenv("ABFT_CG_OVERLAP_BYTES")) least = atoll(env);
   overlap_ = interior && incoming * 8 >= least;
   if (getenv("ABFT_HIP_VERBOSE"))
-    fprintf(stderr, "hip backend: rank %d of %d: rows [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
-            "interior rows [%d,%d)%s\n", me, G, r0_, r0_ + n_loc_, cnt, e0, use_windows_ ? "windows" : "all-gather",
-            comm_->device_collectives() ? "RCCL" : "TCP", interior ? best_lo : 0, interior ? best_hi : 0,
-            overlap_ ? " beside the exchange" : "");
-  return M;
+    fprintf(stderr, "hip backend: rank %d of %d: %s [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
+            "interior rows [%d,%d)%s\n", me, G, format_ == ABFT_FMT_CSR ? "rows" : "columns", r0_, r0_ + n_loc_, cnt,
+            plan.first, use_windows_ ? "windows" : "all-gather", comm_->device_collectives() ? "RCCL" : "TCP",
+            plan.interior_lo, plan.interior_hi, overlap_ ? " beside the exchange" : "");
 }
 
 void HIPContextBase::destroy_matrix(cg_matrix *mat)
@@ -463,8 +471,17 @@ void HIPContextBase::inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_fl
     {
       msg[0] = rand() % mat->nnz;
       int first = 0, width = 96;
-      if (kind == VALUE) width = 64;
-      else if (kind == INDEX) { first = 64; width = 32; }
+      if (format_ == ABFT_FMT_CSR)
+      {
+        if (kind == VALUE) width = 64;
+        else if (kind == INDEX) { first = 64; width = 32; }
+      }
+      else
+      {
+        width = 128;
+        if (kind == VALUE) { first = 64; width = 64; }
+        else if (kind == INDEX) width = 64;
+      }
       for (int i = 0; i < num_flips; i++)
       {
         msg[2 + i] = (rand() % width) + first;
@@ -473,9 +490,21 @@ void HIPContextBase::inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_fl
     }
     comm_->bcast(msg.data(), sizeof(int) * msg.size(), 0);
     const unsigned index = (unsigned)msg[0];
-    if (index >= mat->nnz_before && index < mat->nnz_before + mat->nnz_local)
+    long long local = -1;
+    if (mat->global_index.empty())
+    {
+      if (index >= mat->nnz_before && index < mat->nnz_before + mat->nnz_local)
+        local = (long long)index - mat->nnz_before;
+    }
+    else
+    {
+      std::vector<uint32_t>::const_iterator it = std::lower_bound(mat->global_index.begin(), mat->global_index.end(), index);
+      if (it != mat->global_index.end() && *it == index)
+        local = it - mat->global_index.begin();
+    }
+    if (local >= 0)
       for (int i = 0; i < num_flips; i++)
-        check(abft_hip_inject(mat->handle, index - mat->nnz_before, &msg[2 + i], 1), "abft_hip_inject");
+        check(abft_hip_inject(mat->handle, (uint32_t)local, &msg[2 + i], 1), "abft_hip_inject");
     return;
   }
   int index = rand() % mat->nnz;
@@ -500,4 +529,160 @@ void HIPContextBase::inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_fl
     printf("*** flipping bit %d at index %d ***\n", bit, index);
     check(abft_hip_inject(mat->handle, (uint32_t)index, &bit, 1), "abft_hip_inject");
   }
+}
+
+// ---- CGContextExt ---------------------------------------------------------------------
+
+int HIPContextBase::ext_rank() { return comm_ ? comm_->rank() : 0; }
+int HIPContextBase::ext_size() { return comm_ ? comm_->size() : 1; }
+
+// One iteration with device-resident scalars, enqueue-only (cg.cpp:97-112): the rr of this
+// iteration is pair `parity`, the new one pair 1 - parity, p.w pair 2; alpha = rr / pw and
+// beta = rr_new / rr are formed inside the kernels.
+void HIPContextBase::fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w, int parity)
+{
+  double *cur = fixed_scal_dev_ + 2 * parity, *nxt = fixed_scal_dev_ + 2 * (1 - parity), *pw = fixed_scal_dev_ + 4;
+  void *stream = abft_hip_get_stream(ctx_);
+  if (comm_)
+  {
+    const int off = comm_->rank() * slot_;
+    exchange_begin(p);
+    if (overlap_)
+      check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw, ABFT_PART_INTERIOR),
+            "abft_hip_spmv_dot_part_dev");
+    exchange_finish(p);
+    check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw,
+                                     overlap_ ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
+          "abft_hip_spmv_dot_part_dev");
+    if (comm_->device_collectives())
+      comm_->allreduce_sum_device(pw, 2, stream);
+    else
+      staged_allreduce(pw);
+  }
+  else
+    check(abft_hip_spmv_dot_dev(ctx_, A->handle, p->handle, w->handle, 0, pw), "abft_hip_spmv_dot_dev");
+  check(abft_hip_calc_xr_ratio_dev(ctx_, x->handle, r->handle, p->handle, w->handle, cur, pw, nxt),
+        "abft_hip_calc_xr_ratio_dev");
+  if (comm_)
+  {
+    if (comm_->device_collectives())
+      comm_->allreduce_sum_device(nxt, 2, stream);
+    else
+      staged_allreduce(nxt);
+  }
+  check(abft_hip_calc_p_ratio_dev(ctx_, p->handle, r->handle, nxt, cur), "abft_hip_calc_p_ratio_dev");
+}
+
+// {value, events} on the device summed over ranks through the host (ABFT_COMM=tcp: tests on one GPU)
+void HIPContextBase::staged_allreduce(double *dev_pair)
+{
+  double v[2] = {0.0, 0.0};
+  check(abft_hip_read_pair(ctx_, dev_pair, &v[0], &v[1]), "abft_hip_read_pair");
+  comm_->allreduce_sum(v, 2);
+  check(abft_hip_write_pair(ctx_, dev_pair, v[0], v[1]), "abft_hip_write_pair");
+}
+
+bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w,
+                               int warmup, int steps, double *seconds, double *rr)
+{
+  fused_vec_ = fused_res_ = NULL;
+  if (!fixed_scal_)
+  {
+    check(abft_hip_vector_create(ctx_, 6, &fixed_scal_), "abft_hip_vector_create");
+    fixed_scal_dev_ = (double *)abft_hip_vector_device_ptr(fixed_scal_);
+  }
+  (void)x;
+  // r = b; p = r; rr = r.r  (cg.cpp:87-91), the scalar staying on the device
+  copy_vector(r, b);
+  copy_vector(p, r);
+  check(abft_hip_dot_dev(ctx_, r->handle, r->handle, fixed_scal_dev_), "abft_hip_dot_dev");
+  void *stream = abft_hip_get_stream(ctx_);
+  if (comm_)
+  {
+    if (comm_->device_collectives())
+      comm_->allreduce_sum_device(fixed_scal_dev_, 2, stream);
+    else
+      staged_allreduce(fixed_scal_dev_);
+  }
+  // Replay: the iteration is captured once per parity (the rr pairs swap roles) and launched as
+  // a graph -- kernels, the exchange and both all-reduces are graph nodes.  Not with host-staged
+  // collectives (they synchronise).  ABFT_CG_GRAPH=0 keeps the eager enqueue.  The first two
+  // iterations always run eagerly: communicators and peer connections are set up by their first
+  // use, which must not happen under capture.
+  bool graph = !(comm_ && !comm_->device_collectives());
+  if (const char *env = getenv("ABFT_CG_GRAPH")) graph = graph && strcmp(env, "0") != 0;
+  int done = 0;
+  const int total = warmup + steps;
+  double t0 = 0.0;
+  bool timing = false;
+  for (int it = 0; it < total; it++)
+  {
+    if (it == warmup)
+    {
+      // the timed region: barrier + device synchronisation on both sides
+      check(abft_hip_synchronize(ctx_), "abft_hip_synchronize");
+      if (comm_) comm_->barrier();
+      t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      timing = true;
+    }
+    const int parity = it & 1;
+    if (graph && it >= 2)
+    {
+      if (!fixed_graph_[parity])
+      {
+        int rc = abft_hip_graph_begin(ctx_);
+        if (rc == ABFT_OK)
+        {
+          fixed_iteration(A, x, r, p, w, parity);
+          rc = abft_hip_graph_end(ctx_, &fixed_graph_[parity]);
+        }
+        if (rc != ABFT_OK)
+        {
+          fprintf(stderr, "hip backend: hipGraph capture of the CG iteration failed (%s); running eagerly\n",
+                  abft_hip_last_error());
+          graph = false;
+          fixed_graph_[parity] = NULL;
+          fixed_iteration(A, x, r, p, w, parity);
+          done++;
+          continue;
+        }
+      }
+      check(abft_hip_graph_launch(fixed_graph_[parity]), "abft_hip_graph_launch");
+    }
+    else
+      fixed_iteration(A, x, r, p, w, parity);
+    done++;
+  }
+  check(abft_hip_synchronize(ctx_), "abft_hip_synchronize");
+  if (comm_) comm_->barrier();
+  double dt = timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0 : 0.0;
+  if (comm_)
+  {
+    std::vector<double> all((size_t)comm_->size());
+    comm_->allgather(&dt, sizeof(dt), all.data());
+    for (size_t k = 0; k < all.size(); k++) dt = std::max(dt, all[k]);
+  }
+  double v[2] = {0.0, 0.0};
+  check(abft_hip_read_pair(ctx_, fixed_scal_dev_ + 2 * (done & 1), &v[0], &v[1]), "abft_hip_read_pair");
+  if (getenv("ABFT_BENCH_PROFILE"))
+  {
+    // measurement aid, after the timed region: a few more iterations, enqueued eagerly, with every
+    // SpMV launch bracketed by HIP events on the context's stream (brackets cannot be captured)
+    check(abft_hip_profile_enable(ctx_, 1 << ABFT_K_SPMV), "abft_hip_profile_enable");
+    check(abft_hip_profile_reset(ctx_), "abft_hip_profile_reset");
+    const int extra = 2 * std::max(5, std::min(steps, 20) / 2);
+    for (int it = 0; it < extra; it++)
+      fixed_iteration(A, x, r, p, w, (done + it) & 1);
+    double ms = 0.0;
+    long launches = 0;
+    check(abft_hip_profile_read(ctx_, ABFT_K_SPMV, &ms, &launches), "abft_hip_profile_read");
+    check(abft_hip_profile_enable(ctx_, 0), "abft_hip_profile_enable");
+    printf("bench_spmv: rank %d spmvs %d brackets %ld total_us %.3f local_rows %d local_nnz %u\n", ext_rank(), extra,
+           launches, ms * 1e3, comm_ ? n_loc_ : A->N, A->nnz_local);
+  }
+  if (comm_ || v[1] > 0.0)
+    report_events(true);  // collective across ranks: every rank calls it
+  if (seconds) *seconds = dt;
+  if (rr) *rr = v[0];
+  return true;
 }

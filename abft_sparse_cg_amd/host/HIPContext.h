@@ -23,22 +23,26 @@
 // spmv is preceded by an all-gather of the input vector, dot and calc_xr end in an
 // all-reduce of {partial sum, queued events}, map_vector hands the driver the whole
 // vector, events carry global element indices and are printed once, by rank 0, whose
-// stdout is the job's (the other ranks' is discarded).  CSR only.  See comm.h.
+// stdout is the job's (the other ranks' is discarded).  CSR is cut by row blocks, COO by
+// column blocks (its outputs).  See comm.h and partition.h.
 #pragma once
 #include <vector>
 
 #include "CGContext.h"
+#include "CGContextExt.h"
 #include "abft_hip.h"
 
 class Comm;
+struct ShardPlan;
 
 struct cg_matrix
 {
   abft_hip_matrix *handle;
   unsigned N;
   unsigned nnz;       // of the whole matrix
-  unsigned nnz_local; // sharded: elements of this rank's row block, the first being element nnz_before
+  unsigned nnz_local; // sharded: elements of this rank's block; CSR: the first being element nnz_before
   unsigned nnz_before;
+  std::vector<uint32_t> global_index;  // sharded COO (column blocks): the caller's index of each local element, ascending
 };
 
 struct cg_vector
@@ -50,7 +54,7 @@ struct cg_vector
   double *host_full;        // sharded: map_vector's whole-vector staging
 };
 
-class HIPContextBase : public CGContext
+class HIPContextBase : public CGContext, public CGContextExt
 {
 public:
   HIPContextBase(int format, int mode);
@@ -74,7 +78,19 @@ public:
 
   virtual void inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_flips);
 
+  // ---- CGContextExt: what this repository's driver may use beyond the reference interface ----
+  virtual int ext_rank();
+  virtual int ext_size();
+  virtual cg_matrix* create_matrix_rows(const uint32_t *columns, const uint32_t *rows, const double *values, int N,
+                                        long long nnz_total, const long long *row_bounds, long long elem0,
+                                        long long count);
+  virtual bool run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w,
+                         int warmup, int steps, double *seconds, double *rr);
+
 private:
+  void adopt_plan(cg_matrix *M, const ShardPlan &plan);
+  void staged_allreduce(double *dev_pair);
+  void fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w, int parity);
   void check(int rc, const char *what);
   void report_events(bool force);
   double reduce_scalar(abft_hip_vector *pair);
@@ -97,6 +113,11 @@ private:
   double *pair_dev_;             // ... their address (asked once: see abft_hip_vector_device_ptr)
   const cg_vector *fused_vec_;   // the last spmv also left vec.result in pair_ (until anything else runs)
   const cg_vector *fused_res_;
+  // run_fixed: three {value, events} pairs on the device (rr of even / odd iterations, p.w), and the
+  // captured iteration, one graph per parity
+  abft_hip_vector *fixed_scal_;
+  double *fixed_scal_dev_;
+  abft_hip_graph *fixed_graph_[2];
 };
 
 template<int FORMAT, int MODE>

@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "CGContext.h"
+#include "CGContextExt.h"
 #include "glibc_rand.h"
 #include "matrix_io.h"
 
@@ -42,6 +43,7 @@ struct Options
   bool quiet = false;
   long flip_index = -1;
   std::vector<int> flip_bits;
+  int bench_warmup = -1, bench_steps = 0;  // --bench W,K
 };
 
 double to_double(const char *s)
@@ -93,7 +95,10 @@ void usage(const char *argv0)
          "                              laplace5:NX,NY | random:N,K,SEED | powerlaw:N,SEED\n"
          "      --seed            N     Seed for the -x draws (default: time)\n"
          "      --flip-at  I:B[,B...]   Flip the given bit(s) of matrix element I\n"
-         "  -q  --quiet                 Do not print the per-iteration residual\n");
+         "  -q  --quiet                 Do not print the per-iteration residual\n"
+         "      --bench  W,K            Fixed-iteration run with alpha and beta kept on the device\n"
+         "                              (the loop of -c 0 without per-iteration host round trips):\n"
+         "                              W untimed iterations, then K timed ones; prints a 'bench:' line\n");
   printf("\n");
 }
 
@@ -193,6 +198,12 @@ Options parse(int argc, char *argv[])
     {
       o.quiet = true;
     }
+    else if (is("--bench", NULL))
+    {
+      if (++i >= argc || sscanf(argv[i], "%d,%d", &o.bench_warmup, &o.bench_steps) != 2 || o.bench_warmup < 0 ||
+          o.bench_steps < 1)
+        fail("Invalid --bench (want WARMUP,STEPS)");
+    }
     else if (is("--help", "-h"))
     {
       usage(argv[0]);
@@ -236,6 +247,7 @@ int main(int argc, char *argv[])
   int N = 0, nnz = 0, block_size = 0;
   uint32_t *cols = NULL, *rows = NULL;
   double *vals = NULL;
+  cg_matrix *A = NULL;
   if (o.synthetic)
   {
     int64_t n = abft_gen_dim(o.synthetic);
@@ -248,10 +260,34 @@ int main(int argc, char *argv[])
     N = (int)n;
     nnz = (int)cnt;
     block_size = N;
-    cols = (uint32_t *)malloc((size_t)nnz * sizeof(uint32_t));
-    rows = (uint32_t *)malloc((size_t)nnz * sizeof(uint32_t));
-    vals = (double *)malloc((size_t)nnz * sizeof(double));
-    abft_gen_fill(o.synthetic, 0, n, cols, rows, vals);
+    // several ranks: each generates its own row block only (CSR; a backend that cannot take a
+    // block -- COO, cut by columns -- answers NULL and gets the whole matrix below)
+    CGContextExt *ext = dynamic_cast<CGContextExt *>(context);
+    if (ext && ext->ext_size() > 1 && n >= ext->ext_size())
+    {
+      const int G = ext->ext_size(), me = ext->ext_rank();
+      std::vector<int64_t> bounds((size_t)G + 1);
+      std::vector<long long> lb((size_t)G + 1);
+      if (abft_gen_partition(o.synthetic, G, bounds.data()) == 0)
+      {
+        for (int g = 0; g <= G; g++) lb[g] = bounds[g];
+        const int64_t before = abft_gen_count(o.synthetic, 0, bounds[me], NULL);
+        const int64_t mine = abft_gen_count(o.synthetic, bounds[me], bounds[me + 1], NULL);
+        uint32_t *bc = (uint32_t *)malloc((size_t)(mine + 1) * sizeof(uint32_t));
+        uint32_t *br = (uint32_t *)malloc((size_t)(mine + 1) * sizeof(uint32_t));
+        double *bv = (double *)malloc((size_t)(mine + 1) * sizeof(double));
+        abft_gen_fill(o.synthetic, bounds[me], bounds[me + 1], bc, br, bv);
+        A = ext->create_matrix_rows(bc, br, bv, N, cnt, lb.data(), before, mine);
+        abft_free_triplets(bc, br, bv);
+      }
+    }
+    if (!A)
+    {
+      cols = (uint32_t *)malloc((size_t)nnz * sizeof(uint32_t));
+      rows = (uint32_t *)malloc((size_t)nnz * sizeof(uint32_t));
+      vals = (double *)malloc((size_t)nnz * sizeof(double));
+      abft_gen_fill(o.synthetic, 0, n, cols, rows, vals);
+    }
   }
   else
   {
@@ -266,8 +302,11 @@ int main(int argc, char *argv[])
     if (rc != ABFT_IO_OK)
       fail("Failed to read matrix data");
   }
-  cg_matrix *A = context->create_matrix(cols, rows, vals, N, nnz);
-  abft_free_triplets(cols, rows, vals);
+  if (!A)
+  {
+    A = context->create_matrix(cols, rows, vals, N, nnz);
+    abft_free_triplets(cols, rows, vals);
+  }
 
   printf("\n");
   printf("implementation        = %s-%s\n", o.target, o.mode);
@@ -310,6 +349,25 @@ int main(int argc, char *argv[])
   {
     srand(o.have_seed ? o.seed : (unsigned)time(NULL));
     context->inject_bitflip(A, o.bitflip_kind, o.num_bit_flips);
+  }
+
+  if (o.bench_warmup >= 0)
+  {
+    // --bench: the fixed-iteration loop with device-resident scalars (CGContextExt::run_fixed)
+    CGContextExt *ext = dynamic_cast<CGContextExt *>(context);
+    double seconds = 0.0, rr_last = 0.0;
+    if (!ext || !ext->run_fixed(A, b, x, r, p, w, o.bench_warmup, o.bench_steps, &seconds, &rr_last))
+      fail("--bench is not supported by this implementation");
+    printf("bench: ranks %d warmup %d steps %d seconds %.9f iterations_per_second %.3f rr %a\n", ext->ext_size(),
+           o.bench_warmup, o.bench_steps, seconds, o.bench_steps / seconds, rr_last);
+    context->destroy_matrix(A);
+    context->destroy_vector(b);
+    context->destroy_vector(x);
+    context->destroy_vector(r);
+    context->destroy_vector(p);
+    context->destroy_vector(w);
+    delete context;
+    return 0;
   }
 
   auto t0 = std::chrono::steady_clock::now();

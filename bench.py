@@ -43,8 +43,6 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--profile-all", action="store_true",
                     help="bracket all four kernels, not only the SpMV (costs ~10%% of the iteration rate)")
-    ap.add_argument("--host-scalars", action="store_true",
-                    help="N > 1: return both scalars to the host every iteration (default: device-resident)")
     ap.add_argument("--no-probe", dest="probe", action="store_false",
                     help="skip the streaming-copy bandwidth probe (the measured-peak denominator beside 8 TB/s)")
     ap.add_argument("--no-extras", dest="extras", action="store_false",
@@ -248,95 +246,68 @@ def single(args):
     return dt, n, nnz, roof, kernels, cpu, probe, rr_final, extras
 
 
-def sharded(args):
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+def cpp_job(args, spec, mode, fmt, profile):
+    """One fixed-iteration run of the C++ driver (host/cg-csr | cg-coo --bench W,K) as a child of
+    this rank's process: the row-partitioned path is implemented once, in C++ (HIPContext.cpp,
+    comm*.cpp over RCCL); every rank of the launcher starts the same executable with its own
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and rank 0's stdout carries the result.
+    W untimed iterations, then K timed ones bracketed by a barrier + device synchronisation on
+    both sides, the slowest rank's time (CGContextExt::run_fixed)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "abft_sparse_cg_amd", "host", "cg-" + fmt)
+    if not os.path.exists(exe):
+        raise SystemExit("%s not built (make -C abft_sparse_cg_amd/host)" % exe)
+    env = dict(os.environ)
+    if profile:
+        env["ABFT_BENCH_PROFILE"] = "1"
+    cmd = [exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    if p.returncode != 0:
+        sys.stderr.write(p.stdout[-2000:] + p.stderr[-4000:])
+        raise SystemExit("rank %s: %s exited with status %d" % (os.environ.get("RANK", "0"), " ".join(cmd), p.returncode))
+    out = {"stderr": p.stderr}
+    m = re.search(r"^bench: ranks (\d+) warmup (\d+) steps (\d+) seconds ([0-9.]+) iterations_per_second ([0-9.]+) rr (\S+)$",
+                  p.stdout, re.M)
+    if m:  # rank 0 (the other ranks' stdout is discarded by the backend)
+        out.update(ranks=int(m.group(1)), seconds=float(m.group(4)), rr=float.fromhex(m.group(6)))
+        h = re.search(r"^matrix size +=\s+(\d+) x", p.stdout, re.M)
+        z = re.search(r"^number of non-zeros +=\s+(\d+) ", p.stdout, re.M)
+        out.update(N=int(h.group(1)), nnz=int(z.group(1)))
+        q = re.search(r"^bench_spmv: rank 0 spmvs (\d+) brackets (\d+) total_us ([0-9.]+) local_rows (\d+) local_nnz (\d+)$",
+                      p.stdout, re.M)
+        if q:
+            out["spmv"] = {"spmvs": int(q.group(1)), "brackets": int(q.group(2)), "total_us": float(q.group(3)),
+                           "rows": int(q.group(4)), "nnz": int(q.group(5))}
+    return out
 
-    from abft_sparse_cg_amd import capi, generators
-    from abft_sparse_cg_amd.distributed import HipEngine, ShardedCG
 
+def multi(args):
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d needs WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, args.gpus))
-    if args.fmt != "csr":
-        raise SystemExit("the row-partitioned solver shards CSR; COO runs on one GPU")
-    torch.cuda.set_device(local)
-    if os.environ.get("NCCL_DEBUG") == "VERSION":
-        os.environ.pop("NCCL_DEBUG")  # RCCL's version banner goes to stdout, which carries the one JSON line
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    n = generators.dim(args.spec)
-    bounds = generators.partition(args.spec, world)
-    r0, r1 = bounds[rank], bounds[rank + 1]
-    cols, rows, vals, _ = generators.generate(args.spec, r0, r1)
-    counts = [None] * world
-    dist.all_gather_object(counts, len(vals))
-    nnz = sum(counts)
-    eng = HipEngine(args.mode, "csr", device=local)
-    cg = ShardedCG(eng, cols, rows, vals, bounds, sum(counts[:rank]), args.mode)
-    del cols, rows, vals
-    b_local = generators.reference_rhs(n)[r0:r1]
-    cg.set_rhs(b_local)
-    # -c 0 run: alpha and beta stay on the device (ShardedCG.run_fixed), so an
-    # iteration is enqueue-only; --host-scalars times the loop that returns both
-    # scalars to the host every iteration (ShardedCG.step) instead
-    if args.host_scalars:
-        cg.start()
-        for _ in range(args.warmup):
-            cg.step()
-    else:
-        cg.run_fixed(args.warmup)
-        cg.set_rhs(b_local)
-    # the device-resident loop replays a captured hipGraph per iteration; HIP-event
-    # brackets cannot be captured, so there the SpMV is bracketed in a short eager
-    # run after the timed region instead of inside it
-    replay = not args.host_scalars and bool(cg._graph)
-    if not args.no_profile and not replay:
-        # sampled brackets (an odd stride: a shard with interior rows alternates two launches per SpMV)
-        eng.ctx.profile(1 << capi.K_SPMV, stride=5)
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if args.host_scalars:
-        for _ in range(args.steps):
-            cg.step()
-    else:
-        cg.run_fixed(args.steps)
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    rr_final = cg.rr
-    if not args.no_profile and replay:
-        eng.ctx.profile(1 << capi.K_SPMV)
-        cg.set_rhs(b_local)
-        cg.run_fixed(min(args.steps, 50), graph=False)
-    roof, kernels = None, {}
-    if not args.no_profile:
-        ms, cnt = eng.ctx.profile_read(capi.K_SPMV)
-        if cnt:
-            # a shard that overlaps its exchange multiplies in two launches (beside / after the exchange):
-            # the roofline figure is per SpMV, i.e. on the sum of the parts
-            parts = 2 if cg.overlap else 1
-            us = ms * 1e3 / cnt * parts
-            byts = spmv_bytes("csr", cg.n_loc, counts[rank])
-            ach = byts / us / 1e3
-            kernels["spmv"] = {"avg_us": round(us, 2), "launches": cnt, "launches_per_spmv": parts,
-                               "GBps": round(ach, 1), "rank": rank}
-            roof = {"bound": "hbm", "kernel": "spmv_csr_kernel<%s> (rank 0 shard)" % args.mode,
-                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "avg_launch_us": round(us, 2),
-                    "algorithmic_bytes_per_launch": byts}
-    exchange = "windows" if cg.use_windows else "all_gather"
-    loop = "returned to the host" if args.host_scalars else \
-        "device-resident, %s" % ("hipGraph replay" if replay else "eager enqueue")
-    eng.close()
-    dist.destroy_process_group()
-    return rank, dt, n, nnz, roof, kernels, rr_final, exchange, loop
+    head = cpp_job(args, args.spec, args.mode, args.fmt, not args.no_profile)
+    extra = None
+    if args.extras:
+        # the configuration the multi-GPU target is quoted on (BASELINE.json configs[3]): same path
+        extra = cpp_job(args, "random:4194304,24,1", "secded", "csr", not args.no_profile)
+    if rank != 0:
+        return None
+
+    def leg(job, fmt, mode):
+        d = {"N": job["N"], "nnz": job["nnz"], "it_per_s": round(args.steps / job["seconds"], 2),
+             "ms_per_step": round(job["seconds"] / args.steps * 1e3, 4), "rr_after_last_step": job["rr"]}
+        sp = job.get("spmv")
+        if sp and sp["spmvs"]:
+            us = sp["total_us"] / sp["spmvs"]  # per SpMV of rank 0's shard (all its launches)
+            byts = spmv_bytes(fmt, sp["rows"], sp["nnz"])
+            d["spmv_rank0"] = {"avg_spmv_us": round(us, 2), "launches_per_spmv": sp["brackets"] / sp["spmvs"],
+                               "rows": sp["rows"], "nnz": sp["nnz"], "algorithmic_bytes_per_spmv": byts,
+                               "achieved": round(byts / us / 1e3, 1), "unit": "GB/s",
+                               "frac": round(byts / us / 1e3 / HBM_PEAK_GBPS, 4)}
+        return d
+    return head, leg(head, args.fmt, args.mode), (leg(extra, "csr", "secded") if extra else None)
 
 
 def main():
@@ -360,16 +331,28 @@ def main():
             out["extra_legs"] = extras
         print(json.dumps(out))
         return
-    rank, dt, n, nnz, roof, kernels, rr, exchange, loop = sharded(args)
-    if rank == 0:
+    res = multi(args)
+    if res is not None:
+        head, hl, xl = res
         out = dict(base)
-        out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
-                    "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec), "N": n,
-                               "nnz": nnz, "format": "csr", "mode": args.mode,
-                               "parallelism": "row-block x%d, %s exchange + 2 all-reduce / iteration, scalars %s"
-                                              % (args.gpus, exchange, loop),
-                               "rr_after_last_step": rr},
-                    "roofline": roof, "cpu_baseline": None, "kernels": kernels})
+        sp = hl.get("spmv_rank0")
+        roof = None
+        if sp:
+            roof = {"bound": "hbm", "kernel": "spmv_%s_kernel<%s> (rank 0 shard, bracketed after the timed region)"
+                    % (args.fmt, args.mode), "achieved": sp["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": sp["frac"], "traffic": None, "avg_launch_us": sp["avg_spmv_us"],
+                    "algorithmic_bytes_per_launch": sp["algorithmic_bytes_per_spmv"]}
+        out.update({"value": hl["it_per_s"], "ms_per_step": hl["ms_per_step"],
+                    "config": {"workload": "cg-%s -t hip -m %s, synthetic %s" % (args.fmt, args.mode, args.spec),
+                               "N": hl["N"], "nnz": hl["nnz"], "format": args.fmt, "mode": args.mode,
+                               "parallelism": "%d ranks (one process per GPU, C++ host over RCCL): output blocks cut by "
+                                              "non-zeros, exchange of the search vector + 2 all-reduces per iteration, "
+                                              "scalars device-resident, iteration replayed as a hipGraph" % args.gpus,
+                               "rr_after_last_step": hl["rr_after_last_step"]},
+                    "roofline": roof, "cpu_baseline": None})
+        if xl:
+            xl["workload"] = "cg-csr -t hip -m secded, synthetic random:4194304,24,1 (BASELINE.json configs[3])"
+            out["extra_legs"] = {"config4": xl}
         print(json.dumps(out))
 
 

@@ -117,6 +117,14 @@ int abft_hip_matrix_create_shard(abft_hip_ctx *ctx, int format, int mode,
                                  const uint32_t *columns, const uint32_t *rows,
                                  const double *values, int n_out, int n_in, int nnz,
                                  uint32_t index_base, abft_hip_matrix **mat);
+/* The same for a shard whose elements are not one contiguous run of the caller's element
+ * order (COO split by column blocks: the reference's input is row-major): event indices are
+ * reported as global_index[local element index] (nnz entries, ascending; NULL = as above
+ * with index_base 0). */
+int abft_hip_matrix_create_shard_indexed(abft_hip_ctx *ctx, int format, int mode,
+                                         const uint32_t *columns, const uint32_t *rows,
+                                         const double *values, int n_out, int n_in, int nnz,
+                                         const uint32_t *global_index, abft_hip_matrix **mat);
 /* reference CSR/CPUContext.cpp:46-52 */
 int abft_hip_matrix_destroy(abft_hip_matrix *mat);
 /* How the matrix is stored and run (measurement only): *layout = 0 streaming row blocks,
@@ -200,6 +208,8 @@ int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector 
 /* ... and back: the two doubles at `dev_pair` (after the collective summed them on
  * the context's stream) delivered to the host through the pinned slot it polls. */
 int abft_hip_read_pair(abft_hip_ctx *ctx, const double *dev_pair, double *value, double *events);
+/* ... and the other way (a sum formed on the host, e.g. by host-staged collectives). */
+int abft_hip_write_pair(abft_hip_ctx *ctx, double *dev_pair, double value, double events);
 
 /* Device-scalar forms, for loops that keep alpha and beta on the device (no host
  * round trip per iteration; the row-partitioned solver's fixed-iteration loop):
@@ -234,6 +244,22 @@ int abft_hip_spmv_part(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
                        abft_hip_vector *result, int part);
 int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                                abft_hip_vector *result, int vec_offset, double *dev_result, int part);
+
+/* ---- graph replay ------------------------------------------------------ */
+
+/* Capture everything enqueued on the context's stream between begin and end -- the
+ * asynchronous calls of this library (spmv*, *_dev forms, calc_p*, copy) and whatever the
+ * caller enqueues on abft_hip_get_stream() meanwhile (RCCL collectives) -- into a hipGraph
+ * and replay it with one launch.  Nothing that synchronises may be called in between
+ * (dot / calc_xr with host results, map, drain_events), kernel brackets must be off, and a
+ * calc_xr must be followed by its calc_p inside the same capture.  The fixed-iteration CG
+ * loop of the drivers (-c 0: cg.cpp:94-118 with alpha and beta kept on the device) is
+ * captured this way. */
+typedef struct abft_hip_graph abft_hip_graph;
+int abft_hip_graph_begin(abft_hip_ctx *ctx);
+int abft_hip_graph_end(abft_hip_ctx *ctx, abft_hip_graph **graph);
+int abft_hip_graph_launch(abft_hip_graph *graph);
+int abft_hip_graph_destroy(abft_hip_graph *graph);
 
 /* ---- events ------------------------------------------------------------ */
 

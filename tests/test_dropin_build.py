@@ -24,20 +24,22 @@ def test_hipcontext_links_into_reference_driver(tmp_path, fmt):
     d = str(tmp_path)
     os.makedirs(os.path.join(d, fmt))
     shutil.copy(os.path.join(ROOT, "include", "abft_hip.h"), d)
-    for f in ("HIPContext.h", "HIPContext.cpp", "comm.h", "comm.cpp", "comm_rccl.cpp"):
+    for f in ("HIPContext.h", "HIPContext.cpp", "CGContextExt.h", "partition.h", "partition.cpp", "comm.h", "comm.cpp",
+              "comm_rccl.cpp"):
         shutil.copy(os.path.join(PKG, "host", f), d)
     shutil.copy(os.path.join(PKG, "host", fmt, "HIPContext.cpp"), os.path.join(d, fmt))
     cxx = ["g++", "-std=gnu++11", "-I", d, "-I", REF, "-O1", "-Wall", "-Werror", "-fopenmp"]
     subprocess.check_call(cxx + ["-c", os.path.join(d, "HIPContext.cpp"), "-o", os.path.join(d, "HIPContext.o")])
-    # the multi-GPU plumbing: plain sockets; comm_rccl.cpp without -DABFT_WITH_RCCL is a stub (no ROCm headers)
-    for f in ("comm", "comm_rccl"):
+    # the multi-GPU plumbing: plain sockets, the partition arithmetic; comm_rccl.cpp without -DABFT_WITH_RCCL is a
+    # stub (no ROCm headers)
+    for f in ("comm", "comm_rccl", "partition"):
         subprocess.check_call(cxx + ["-c", os.path.join(d, f + ".cpp"), "-o", os.path.join(d, f + ".o")])
     subprocess.check_call(cxx + ["-c", os.path.join(d, fmt, "HIPContext.cpp"), "-o", os.path.join(d, fmt, "reg.o")])
     exe = os.path.join(d, "cg")
     subprocess.check_call(["g++", "-std=gnu++11", "-I", REF, "-O1", "-fno-strict-aliasing", "-fopenmp", "-w",
                            os.path.join(REF, "cg.cpp"), os.path.join(REF, "CGContext.cpp"),
                            os.path.join(REF, fmt, "CPUContext.cpp"), os.path.join(d, "HIPContext.o"),
-                           os.path.join(d, "comm.o"), os.path.join(d, "comm_rccl.o"),
+                           os.path.join(d, "comm.o"), os.path.join(d, "comm_rccl.o"), os.path.join(d, "partition.o"),
                            os.path.join(d, fmt, "reg.o"), "-x", "c", os.path.join(REF, "mmio.c"), "-x", "none",
                            "-L" + PKG, "-labft_hip", "-Wl,-rpath," + PKG, "-o", exe])
     out = subprocess.run([exe, "--list"], capture_output=True, text=True).stdout

@@ -119,32 +119,22 @@ def test_synthetic_input_and_fixed_iterations():
     assert "iteration " not in out.stdout
 
 
-def run_py(args, sharded=False):
+def run_py(args):
     env = dict(os.environ, PYTHONPATH=ROOT)
     if "-t" not in args:
         args = ["-t", "hip"] + args
-    if sharded:
-        env["ABFT_CG_SHARDED"] = "1"
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-               "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000), "-m", "abft_sparse_cg_amd.cg"] + args
-    else:
-        cmd = [sys.executable, "-m", "abft_sparse_cg_amd.cg"] + args
+    cmd = [sys.executable, "-m", "abft_sparse_cg_amd.cg"] + args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
 
 
-@pytest.mark.parametrize("sharded", [False, True])
-def test_python_driver_transcripts_match_reference(sharded):
-    """abft_sparse_cg_amd.cg (single process, and the row-partitioned path with one
-    rank over RCCL) prints what the reference cg-csr prints on the same input."""
+def test_python_driver_transcripts_match_reference():
+    """abft_sparse_cg_amd.cg prints what the reference cg-csr prints on the same input."""
     runs = {tuple(r["args"]): r for r in json.load(open(os.path.join(G, "cli.json"))) if r["fmt"] == "csr"}
     for args in (["-b", "1", "-m", "none"], ["-b", "4", "-m", "secded"]):
-        out = run_py(["-f", MTX] + args, sharded)
+        out = run_py(["-f", MTX] + args)
         assert out.returncode == 0, out.stdout[-800:] + out.stderr[-2000:]
-        text = out.stdout
-        if sharded:  # RCCL prints a version banner on stdout when the communicator is created
-            text = text[text.index("\nimplementation"):]
-        compare_transcripts(text, runs[tuple(args)]["stdout"])
-    out = run_py(["-f", MTX, "-b", "1", "-m", "sed", "--flip-at", "77:3"], sharded)
+        compare_transcripts(out.stdout, runs[tuple(args)]["stdout"])
+    out = run_py(["-f", MTX, "-b", "1", "-m", "sed", "--flip-at", "77:3"])
     assert out.returncode == 1, out.stdout[-500:] + out.stderr[-1500:]
     assert out.stdout.rstrip("\n").endswith("[ECC] error detected at index 77")
     assert "*** flipping bit 3 at index 77 ***" in out.stdout
@@ -276,11 +266,69 @@ def test_cpp_driver_row_partitioned_under_torchrun():
     assert sum(l.startswith("hip backend: rank") for l in many.stderr.splitlines()) == 2
 
 
-def test_cpp_coo_driver_refuses_several_ranks_loudly():
-    cmd = [os.path.join(HOST, "mgpu-run"), "2", "--one-gpu", "--", exe("coo"), "-t", "hip", "-m", "none", "-f", MTX]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
-    assert p.returncode == 2
-    assert "shards CSR" in p.stderr and "ran for" not in p.stdout
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mode,flip", [("none", None), ("secded", "1234:70"), ("sec7", "20000:13"), ("none", "777:3")])
+def test_cpp_coo_driver_column_partitioned(world, mode, flip):
+    """cg-coo across ranks: the matrix cut by blocks of its outputs (columns),
+    each rank's elements scattered over the row-major input and reported with their global
+    index -- same report, iteration count, rr history (1e-10) and ECC line as one process.
+    ("none" + 777:3 flips a low column bit: within a rank's block the product moves to the
+    corrupted column as in the reference.)"""
+    args = ["-f", MTX, "-t", "hip", "-m", mode] + (["--flip-at", flip] if flip else [])
+    one = run("coo", args, env={"ABFT_CG_HEX": "1"})
+    many = run_ranks(world, args, ("--one-gpu",), fmt="coo")
+    assert one.returncode == 0 and many.returncode == 0, many.stdout[-400:] + many.stderr[-800:]
+    (rr1, rest1), (rrn, restn) = split_transcript(one.stdout), split_transcript(many.stdout)
+    assert len(rr1) == len(rrn) > 50
+    h1, hn = hex_history(one.stderr), hex_history(many.stderr)
+    for it in h1:
+        assert len(hn[it]) == world and len(set(hn[it])) == 1, it
+        assert abs(hn[it][0] - h1[it][0]) <= 1e-10 * h1[it][0], it
+    norm = lambda t: re.sub(r"(total error|max error) += +[0-9.]+", lambda m: m.group(0)[:-2], t).lstrip("\n")  # noqa: E731
+    assert norm(rest1) == norm(restn)
+    notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
+    assert len(notes) == world and all(" columns [" in l for l in notes)
+
+
+def test_run_tests_script_passes_column_partitioned_coo():
+    launcher = "%s 2 --one-gpu -- %s" % (os.path.join(HOST, "mgpu-run"), exe("coo"))
+    p = subprocess.run([os.path.join(HOST, "run_tests"), launcher], capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, p.stdout
+    assert "FAILED" not in p.stdout and p.stdout.count("passed") >= 7 + 1 + 4 * 3 + 1
+
+
+def bench_line(out):
+    m = re.search(r"^bench: ranks (\d+) warmup (\d+) steps (\d+) seconds ([0-9.]+) iterations_per_second ([0-9.]+) rr (\S+)$",
+                  out, re.M)
+    assert m, out[-600:]
+    return int(m.group(1)), int(m.group(2)), int(m.group(3)), float(m.group(4)), float.fromhex(m.group(6))
+
+
+@pytest.mark.parametrize("spec,mode", [("laplace5:300,300", "secded"), ("random:16384,12,3", "sec8")])
+def test_bench_mode_device_scalars_and_graph_replay(spec, mode):
+    """--bench W,K (CGContextExt::run_fixed): alpha and beta stay on the device, the iteration is
+    captured into a hipGraph and replayed.  After W + K iterations rr equals the driver's own
+    -c 0 loop to 1e-10; replay and eager enqueue give the same bits; the partitioned path at
+    world size 1 (collectives on RCCL inside the captured graph) and at 2 and 3 ranks (one GPU,
+    host-staged collectives, each rank generating only its own row block) agree too."""
+    loop = run("csr", ["-s", spec, "-m", mode, "-c", "0", "-i", "25"], env={"ABFT_CG_HEX": "1"})
+    assert loop.returncode == 0
+    want = hex_history(loop.stderr)[24][0]
+    base = ["-s", spec, "-m", mode, "--bench", "5,20", "-q"]
+    replay = run("csr", base)
+    eager = run("csr", base, env={"ABFT_CG_GRAPH": "0"})
+    assert replay.returncode == 0 and eager.returncode == 0, replay.stdout[-400:] + replay.stderr[-800:]
+    g, w, k, sec, rr = bench_line(replay.stdout)
+    assert (g, w, k) == (1, 5, 20) and sec > 0 and abs(rr - want) <= 1e-10 * want
+    assert bench_line(eager.stdout)[4] == rr
+    forced = run_ranks(1, ["-t", "hip"] + base)
+    assert forced.returncode == 0, forced.stderr[-800:]
+    assert abs(bench_line(forced.stdout)[4] - want) <= 1e-10 * want and "over RCCL" in forced.stderr
+    for world in (2, 3):
+        many = run_ranks(world, ["-t", "hip"] + base, ("--one-gpu",))
+        assert many.returncode == 0, many.stderr[-800:]
+        gg, _, _, _, rrn = bench_line(many.stdout)
+        assert gg == world and abs(rrn - want) <= 1e-10 * want
 
 
 def test_config3_cli_sed_x_index_full_size():
@@ -308,3 +356,17 @@ def test_run_benchmark_script(fmt):
     assert [r[0] for r in rows] == ["hip-" + m for m in ("none", "constraints", "sed", "sec7", "sec8", "secded", "sec")]
     for _, mean, lo, hi in rows:
         assert 0.0 < float(lo) <= float(mean) <= float(hi)
+
+
+def test_bench_py_multi_rank_path_runs_the_cpp_driver():
+    """bench.py --gpus N (N > 1 under the launcher) starts host/cg-csr --bench per rank; here the
+    same code path with one rank (collectives forced onto RCCL), small matrix, no extra leg."""
+    env = dict(os.environ, ABFT_BENCH_SHARDED="1", ABFT_COMM_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(21000 + os.getpid() % 9000))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3",
+                        "--spec", "laplace5:300,300", "--mode", "secded", "--no-extras"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-500:] + p.stderr[-1500:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0 and d["config"]["N"] == 90000
+    assert d["roofline"]["avg_launch_us"] > 0 and "C++ host over RCCL" in d["config"]["parallelism"]

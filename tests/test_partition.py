@@ -1,0 +1,109 @@
+"""The multi-rank decomposition on the CPU: the partition planner the C++ host uses
+(host/partition.cpp, through libabft_host.so) checked property by property, and a whole
+row-/column-partitioned CG run with world sizes 2 and 3 over torch.distributed (gloo), numpy
+standing in for the GPU kernels -- same iteration count and residual history (1e-10) as one
+process.  (The real kernels run the same shard geometry on the one GPU in test_gpu_cli.py.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from _oracle import COO, CSR, OracleMatrix, laplace5, random_spd, rhs
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+WORKER = os.path.join(HERE, "_partition_worker.py")
+
+
+def lib():
+    import ctypes as C
+    return C.CDLL(os.path.join(ROOT, "abft_sparse_cg_amd", "libabft_host.so"))
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+@pytest.mark.parametrize("matrix", ["laplace", "random"])
+def test_planner_properties(fmt, world, matrix):
+    from _partition_worker import local_spmv, plan
+    cols, rows, vals, n = laplace5(40, 33) if matrix == "laplace" else random_spd(900, 9, seed=4)
+    L = lib()
+    plans = [plan(L, fmt, cols, rows, vals, n, world, me) for me in range(world)]
+    out, gat = (rows, cols) if fmt == 0 else (cols, rows)
+    b = plans[0]["bounds"]
+    assert b[0] == 0 and b[-1] == n and all(b[g + 1] > b[g] for g in range(world))
+    assert all(np.array_equal(p["bounds"], b) for p in plans)
+    slot = max(b[g + 1] - b[g] for g in range(world))
+    seen = np.zeros(len(vals), int)
+    x = rhs(n, 3) - 0.5
+    want = OracleMatrix(CSR if fmt == 0 else COO, "none", cols, rows, vals, n).spmv(x)
+    xpad = np.zeros(slot * world)
+    for g in range(world):
+        xpad[g * slot:g * slot + b[g + 1] - b[g]] = x[b[g]:b[g + 1]]
+    counts = []
+    for me, p in enumerate(plans):
+        assert p["slot"] == slot and p["n_pad"] == slot * world and p["out0"] == b[me] and p["n_loc"] == b[me + 1] - b[me]
+        g = p["gidx"]
+        assert np.all(np.diff(g.astype(np.int64)) > 0)  # ascending: the caller's order is kept
+        if fmt == 0:
+            assert np.array_equal(g, p["first"] + np.arange(p["nnz"]))  # CSR: one contiguous run
+        seen[g] += 1
+        assert np.array_equal(p["lout"], out[g] - b[me])
+        owner = np.searchsorted(b, gat[g], side="right") - 1
+        assert np.array_equal(p["pin"], owner * slot + (gat[g] - b[owner]))
+        # the windows cover every remote read, the interior rows read nothing remote
+        for k in np.nonzero(owner != me)[0]:
+            lo, hi = p["need"][owner[k]]
+            assert lo <= gat[g][k] - b[owner[k]] < hi
+        lo, hi = p["interior"]
+        inside = (p["lout"] >= lo) & (p["lout"] < hi)
+        assert np.all(owner[inside] == me)
+        # the shard's SpMV on the padded vector = its rows of the whole product, bit for bit
+        y = local_spmv(p, vals[g], xpad)
+        assert np.array_equal(y.view(np.uint64), want[b[me]:b[me + 1]].view(np.uint64))
+        counts.append(p["nnz"])
+    assert np.all(seen == 1)
+    if world > 1 and matrix == "random":
+        assert max(counts) < 1.3 * len(vals) / world  # cut by non-zeros, not by rows
+
+
+def run_world(world, fmt, matrix):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), str(fmt), matrix],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=240))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                if q.poll() is None:
+                    q.kill()
+            pytest.fail("rank job timed out")
+    assert [p.returncode for p in procs] == [0] * world, outs[0][1][-2000:]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT ")][-1]
+    return json.loads(line[7:])
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("matrix", ["laplace", "random"])
+def test_partitioned_cg_over_gloo_matches_one_process(fmt, world, matrix):
+    cols, rows, vals, n = laplace5(40, 33) if matrix == "laplace" else random_spd(900, 9, seed=4)
+    o = OracleMatrix(CSR if fmt == 0 else COO, "none", cols, rows, vals, n)
+    it, hist, x, fatal = o.cg(rhs(n, 1))
+    out = run_world(world, fmt, matrix)
+    assert out["it"] == it
+    assert np.allclose(out["hist"], hist, rtol=1e-10, atol=0)
+    assert np.abs(np.array(out["x"]) - x).max() <= 1e-10 * np.abs(x).max()
+    assert out["windows"] == (matrix == "laplace")  # banded: halo windows; scattered: all-gather
+    if matrix == "laplace":
+        lo, hi = out["interior"]
+        assert hi - lo > (out["bounds"][1] - out["bounds"][0]) // 2
