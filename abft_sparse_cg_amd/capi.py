@@ -82,6 +82,8 @@ SIGNATURES = {
     "abft_hip_calc_xr_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "abft_hip_calc_p_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp]),
     "abft_hip_write_pair": (C.c_int, [vp, vp, C.c_double, C.c_double]),
+    "abft_hip_matrix_panels": (C.c_int, [vp, i32p, i32p]),
+    "abft_hip_spmv_dot_range_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]),
     "abft_hip_graph_begin": (C.c_int, [vp]),
     "abft_hip_graph_end": (C.c_int, [vp, vpp]),
     "abft_hip_graph_launch": (C.c_int, [vp]),

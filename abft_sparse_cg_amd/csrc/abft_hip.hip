@@ -95,7 +95,7 @@ struct abft_hip_matrix {
   bool use_sweep = false;           // sweep layout (one persistent launch; see SweepLayout)
   SweepLayout sweep{};
   int sweep_rpt = 8;
-  uint32_t sweep_grid = 0;
+  uint32_t sweep_grid = 0, sweep_width = 0;
   // streaming CSR: host copy of the row-block descriptors, and the tiles [t_lo, t_hi)
   // made of interior rows only (abft_hip_matrix_set_interior; empty by default)
   std::vector<uint4> blk_host;
@@ -444,9 +444,25 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
   const bool force = env && !strcmp(env, "sweep");
   if ((env && strcmp(env, "sweep") && strcmp(env, "auto")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0)
     return false;
-  uint32_t width = 1u << 17;  // entries of the gathered vector per panel: 1 MB (2 MB: 757 vs 743 us on config 4)
-  if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
   if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
+  // rows per thread: the smallest group size whose groups are all resident at once
+  sb.rpt = 16;
+  for (int rpt : {2, 4, 8})
+    if (((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt) <= capacity(rpt)) { sb.rpt = rpt; break; }
+  if (const char *r = getenv("ABFT_HIP_SWEEP_RPT")) {
+    const int v = atoi(r);
+    if (v == 2 || v == 4 || v == 8 || v == 16) sb.rpt = v;
+  }
+  // entries of the gathered vector per panel: 1 MB of it (2 MB: 757 vs 743 us on config 4) unless that
+  // leaves a segment well under two tiles on average -- the 1/8 row shard of config 4 that one rank
+  // of an 8-GPU job multiplies: 161 us with 1 MB panels, 134 us with 2 MB ones
+  uint32_t width = 1u << 17;
+  {
+    const uint64_t groups = ((uint64_t)n_out + 256u * sb.rpt - 1) / (256u * sb.rpt);
+    const uint64_t tile = 256u * (sb.rpt <= 4 ? 4u : 8u);
+    if ((uint64_t)nnz * 2 < 3 * tile * groups * (((uint64_t)n_in + width - 1) / width)) width = 1u << 18;
+  }
+  if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
   const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
   if (npanels == 0 || (uint64_t)n_out * npanels > ((uint64_t)1 << 31)) return false;
   // one count per (row, panel) must stay small next to the matrix itself
@@ -472,14 +488,6 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
       for (uint64_t c = 0; c < npanels; c++) nonempty += seen[c];
     }
     if (nonempty < 3 * g2k) return false;
-  }
-  // rows per thread: the smallest group size whose groups are all resident at once
-  sb.rpt = 16;
-  for (int rpt : {2, 4, 8})
-    if (((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt) <= capacity(rpt)) { sb.rpt = rpt; break; }
-  if (const char *r = getenv("ABFT_HIP_SWEEP_RPT")) {
-    const int v = atoi(r);
-    if (v == 2 || v == 4 || v == 8 || v == 16) sb.rpt = v;
   }
   const uint32_t G = 256u * (uint32_t)sb.rpt, WR = 64u * (uint32_t)sb.rpt;
   const uint64_t ngroups = ((uint64_t)n_out + G - 1) / G, nseg = ngroups * npanels;
@@ -535,6 +543,7 @@ static int finish_sweep(abft_hip_matrix *m, const SweepBuild &sb, uint32_t capac
   HIPCHK(hipStreamSynchronize(m->ctx->stream));  // `init` goes out of scope
   m->use_sweep = true;
   m->sweep_rpt = sb.rpt;
+  m->sweep_width = sb.width;
   m->sweep.wbase = d_wbase;
   m->sweep.counts = d_counts;
   m->sweep.ngroups = sb.ngroups;
@@ -715,6 +724,19 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     return rc;
   }
   A.elems = d_el; A.grp_ptr = d_grp; A.blk = d_blk; A.orig_index = d_orig; A.pos_of_orig = d_pos;
+  if (mode == ABFT_MODE_CONSTRAINTS) {  // where each stored element's caller-order successor is stored
+    // (one entry more than elements: lanes past a tile's end read the entry of its first position,
+    // which for an empty tile at the end of the matrix is position nnz)
+    std::vector<uint32_t> succ((size_t)nnz + 1, 0xffffffffu);
+    for (int i = 0; i + 1 < nnz; i++) succ[pos[i]] = pos[i + 1];
+    uint32_t *d_succ = nullptr;
+    if ((rc = dev_upload(m, &d_succ, succ.data(), succ.size(), succ.size()))) {
+      matrix_free(m);
+      return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // `succ` goes out of scope
+    A.succ_pos = d_succ;
+  }
   if (panels) {
     uint32_t *d_segbase = nullptr;
     uint16_t *d_segptr = nullptr;
@@ -837,7 +859,7 @@ extern "C" int abft_hip_matrix_info(abft_hip_matrix *mat, int *layout, int *laun
     int n = 1;
     if (mat->use_panels && mat->panel_chunk && mat->panels.npanels)
       n = (int)((mat->panels.npanels + mat->panel_chunk - 1) / mat->panel_chunk);
-    if (mat->fmt == ABFT_FMT_COO) n += 1;  // coo_fixup_kernel (returns at once on clean data)
+    // (COO: the corrupted-column fix-up rides in the fold of the fused product; without one it is a launch of its own)
     *launches_per_spmv = n;
   }
   return ABFT_OK;
@@ -1189,7 +1211,8 @@ extern "C" int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, 
 // Shared by abft_hip_spmv (dev_pair == nullptr: the fused product, if any, goes to
 // the pinned slot for a following dot) and abft_hip_spmv_dot_dev.
 static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
-                       abft_hip_vector *result, int vec_offset, double *dev_pair, int part = ABFT_PART_ALL) {
+                       abft_hip_vector *result, int vec_offset, double *dev_pair, int part = ABFT_PART_ALL,
+                       int c0 = 0, int c1 = -1) {
   if (int rc = bind(ctx)) return rc;
   if (!mat || !vec || !result) return set_err(ABFT_ERR_INVALID, "spmv: null argument");
   if (part < ABFT_PART_ALL || part > ABFT_PART_BOUNDARY) return set_err(ABFT_ERR_INVALID, "spmv: unknown part %d", part);
@@ -1207,11 +1230,20 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   FuseOut fuse{};
   const bool to_host = !dev_pair && ctx->fuse_enabled && n_in == n_out && (uint32_t)vec->n == n_in &&
                        (uint32_t)result->n == n_out;
-  const bool do_fuse = mat->fuse_partials && (dev_pair || to_host);
-  if (dev_pair && !do_fuse) return set_err(ABFT_ERR_INVALID, "spmv_dot: matrix has no rows");
+  const bool want_fuse = mat->fuse_partials && (dev_pair || to_host);
+  if (dev_pair && !want_fuse) return set_err(ABFT_ERR_INVALID, "spmv_dot: matrix has no rows");
   // tiles of this call (streaming CSR only; other layouts have no interior part)
   const uint32_t n_int = mat->t_hi - mat->t_lo;
   if (part == ABFT_PART_INTERIOR && n_int == 0) return ABFT_OK;  // nothing to run ahead of the exchange
+  // a range of column panels (layouts that sweep panels): [c0, c1) of them, the sums of an
+  // earlier range carried in `result`; the fused product belongs to the range that ends the sweep
+  const uint32_t npan = mat->use_sweep ? mat->sweep.npanels : 1u;  // (the other layouts run whole)
+  const bool whole = c1 < 0;
+  if (whole) { c0 = 0; c1 = (int)npan; }
+  if (c0 < 0 || c0 >= c1 || (uint32_t)c1 > npan) return set_err(ABFT_ERR_INVALID, "spmv: panels [%d,%d) outside [0,%u)", c0, c1, npan);
+  if (!whole && part != ABFT_PART_ALL) return set_err(ABFT_ERR_INVALID, "spmv: a panel range with a row part");
+  const bool last_range = (uint32_t)c1 == npan;
+  const bool do_fuse = want_fuse && last_range;
   TileSpan span{0u, mat->csr.nblk, 0u, mat->csr.nblk};
   if (part == ABFT_PART_INTERIOR) span = TileSpan{mat->t_lo, n_int, 0u, n_int};
   else if (part == ABFT_PART_BOUNDARY && n_int) span = TileSpan{0u, mat->t_lo, n_int, mat->csr.nblk - n_int};
@@ -1224,12 +1256,13 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
     fuse.x_off = dev_pair ? (uint32_t)vec_offset : 0u;
   }
   uint32_t nparts = mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk;
+  FixArgs fix{};
   {
     KernelTimer t(ctx, ABFT_K_SPMV);
     if (mat->use_sweep) {
       nparts = mat->sweep_grid;
       HIPCHK(launch_spmv_sweep(mat->mode, mat->sweep_rpt, mat->csr, mat->sweep, vec->d, result->d, ctx->ring,
-                               do_fuse ? &fuse : nullptr, mat->sweep_grid, 0u, mat->sweep.npanels, ctx->stream));
+                               do_fuse ? &fuse : nullptr, mat->sweep_grid, (uint32_t)c0, (uint32_t)c1, ctx->stream));
     } else if (mat->fmt == ABFT_FMT_CSR && mat->use_panels) {
       nparts = mat->panel_grid;
       HIPCHK(launch_spmv_csr_panels(mat->mode, mat->csr, mat->panels, vec->d, result->d, ctx->ring,
@@ -1243,18 +1276,21 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
                              ctx->stream));
     else
       HIPCHK(launch_spmv_coo(mat->mode, mat->coo, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
-    // products whose stored column was silently corrupted go where the reference puts them
-    if (mat->fmt == ABFT_FMT_COO)
-      HIPCHK(launch_coo_fixup(mat->mode, mat->coo, mat->use_panels ? &mat->panels : nullptr, vec->d, result->d,
-                              ctx->ring, do_fuse ? &fuse : nullptr, ctx->stream));
+    // COO: products whose stored column was silently corrupted go where the reference puts them --
+    // inside the fold of the fused product below when there is one, else as a launch of its own
+    if (mat->fmt == ABFT_FMT_COO) {
+      fix = make_fix_args(mat->mode, mat->coo, mat->use_panels ? &mat->panels : nullptr, vec->d, result->d,
+                          do_fuse ? &fuse : nullptr);
+      if (!do_fuse) HIPCHK(launch_coo_fixup(fix, ctx->stream));
+    }
   }
-  if (part == ABFT_PART_INTERIOR) return ABFT_OK;  // the boundary call folds and publishes
+  if (part == ABFT_PART_INTERIOR || !last_range) return ABFT_OK;  // the call that completes the product folds and publishes
   if (do_fuse) {
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
     ReduceOut big{};  // same outputs as the one-block fold, reached through the reduction protocol
     big.partials = ctx->partials; big.ticket = ctx->ticket; big.dev_out = fuse.dev_out; big.host = fuse.host;
     big.ev_count = fuse.ev_count; big.seq = fuse.seq;
-    HIPCHK(launch_fuse_finalize(fuse, nparts, big, ctx->stream));
+    HIPCHK(launch_fuse_finalize(fuse, nparts, big, fix.on ? &fix : nullptr, ctx->stream));
   }
   if (to_host && do_fuse) {
     ctx->fused.valid = true;
@@ -1276,6 +1312,19 @@ extern "C" int abft_hip_spmv_dot_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, co
                                      abft_hip_vector *result, int vec_offset, double *dev_result) {
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
   return spmv_common(ctx, mat, vec, result, vec_offset, dev_result);
+}
+
+extern "C" int abft_hip_matrix_panels(abft_hip_matrix *mat, int *npanels, int *width) {
+  if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
+  if (npanels) *npanels = mat->use_sweep ? (int)mat->sweep.npanels : 1;
+  if (width) *width = mat->use_sweep ? (int)mat->sweep_width : (int)(mat->fmt == ABFT_FMT_CSR ? mat->csr.n_in : mat->coo.n_in);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_spmv_dot_range_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                                           abft_hip_vector *result, int vec_offset, double *dev_result, int c0, int c1) {
+  if (c1 < 0) return set_err(ABFT_ERR_INVALID, "spmv range: bad panel range");
+  return spmv_common(ctx, mat, vec, result, vec_offset, dev_result, ABFT_PART_ALL, c0, c1);
 }
 
 extern "C" int abft_hip_spmv_part(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,

@@ -98,6 +98,7 @@ struct CooDev {
   const uint4 *blk;             // nblk : {first group, end group, first element, end element}
   const uint32_t *orig_index;   // stored position -> caller's element index (cold path)
   const uint32_t *pos_of_orig;  // caller's element index -> stored position
+  const uint32_t *succ_pos;     // constraints mode: stored position of the caller-order successor (~0u: none)
   uint32_t nblk, n_out, n_in, nnz, index_base;
   MovedList moved;
   const uint32_t *gidx;         // column-block shards: global (caller's) index of local element k; else index_base + k
@@ -214,14 +215,32 @@ hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P,
                                   hipStream_t s);
 // fuse == nullptr: plain SpMV; otherwise follow with launch_fuse_finalize
 // (`big`: where a multi-workgroup fold of many partials meets; see fold_partials_kernel)
-hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, const ReduceOut &big, hipStream_t s);
+struct FixArgs;
+hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, const ReduceOut &big, const FixArgs *fix, hipStream_t s);
 hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);
 hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
                            const FuseOut *fuse, hipStream_t s);
-// behind every COO SpMV (and before the fold of a fused product): see MovedList
-hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, EventRing ev,
-                            const FuseOut *fuse, hipStream_t s);
+// behind every COO SpMV: see MovedList.  With a fused product the fix-up runs inside the fold
+// (launch_fuse_finalize's `fix`), else as its own one-workgroup launch.
+// where output c's own elements sit: the one group (streaming layout), or its slice of
+// segment (group, panel rg) in the panel layout
+struct FixLayout {
+  int kind;  // 0 streaming, 1 panels
+  CsrPanels P;
+};
+struct FixArgs {
+  CooDev A;
+  FixLayout F;
+  const double *x;
+  double *y;
+  double *partial0;  // the fused product's partial 0 (corrected in place), or nullptr
+  uint32_t x_off;
+  int ecc;           // the stored column carries ECC bits (mask them)
+  int on;            // 0: nothing to do (not a COO matrix)
+};
+FixArgs make_fix_args(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, const FuseOut *fuse);
+hipError_t launch_coo_fixup(const FixArgs &fx, hipStream_t s);
 
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);

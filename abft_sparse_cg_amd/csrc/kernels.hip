@@ -210,6 +210,10 @@ hipError_t launch_encode_coo(int mode, uint4 *elems, uint32_t nnz, hipStream_t s
   return hipGetLastError();
 }
 
+// ---------------------------------------------- COO fix-up (defined further down) --
+
+__device__ void coo_fixup_body(const FixArgs &fx);
+
 // ------------------------------------------------------ fused dot epilogue --
 
 // Tail of an SpMV launched with a FuseOut: `dsum` is this thread's share of
@@ -226,8 +230,9 @@ __device__ __forceinline__ void fused_dot_finish(double dsum, const FuseOut &f, 
   if (threadIdx.x == 0) f.partials[slot] = bsum;
 }
 
-__global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t nblk) {
+__global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t nblk, FixArgs fx) {
   __shared__ double s_w[16];
+  if (fx.on) coo_fixup_body(fx);  // COO: moved products first (it corrects partial 0); returns at once on clean data
   // fixed order; sixteen independent loads in flight per thread
   double acc = 0.0;
   for (uint32_t i = threadIdx.x; i < nblk; i += 16u * 1024u) {
@@ -690,21 +695,44 @@ __device__ __forceinline__ void coo_consume(const CooDev &A, const double *__res
   uint32_t row[EPT];
   double val[EPT];
   bool ok[EPT];
+  // constraints mode compares every element with its successor in the CALLER's order
+  // (reference COO/CPUContext.cpp:170-186), which sits somewhere else in the grouped storage:
+  // its stored position comes from a table built at create time (one coalesced 4-byte load per
+  // element; ~0u: no successor), then one 8-byte gather of its {col,row}.  Issued for the whole
+  // tile before any check, branch-free, so that the gathers run together.  (Through the two
+  // permutation arrays -- two dependent gathers per element -- this mode took 2.3x the time of
+  // every other one.)
+  uint2 nxt_cr[MODE == MODE_CONSTRAINTS ? EPT : 1];
+  bool has_nxt[MODE == MODE_CONSTRAINTS ? EPT : 1];
+  if (MODE == MODE_CONSTRAINTS) {
+    uint32_t sp[EPT];
+#pragma unroll
+    for (int s = 0; s < EPT; s++) {
+      const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
+      sp[s] = A.succ_pos[j < hi ? j : lo];
+    }
+#pragma unroll
+    for (int s = 0; s < EPT; s++) {
+      has_nxt[s] = sp[s] != 0xffffffffu;
+      nxt_cr[s] = *reinterpret_cast<const uint2 *>(A.elems + (has_nxt[s] ? sp[s] : lo));
+    }
+  }
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
     uint32_t w[4] = {t.e[s].x, t.e[s].y, t.e[s].z, t.e[s].w};
     bool valid = j < hi;
     if (MODE == MODE_CONSTRAINTS) {
-      if (valid) {  // per-element structural checks: a cold, gather-heavy mode by nature
-        const uint32_t i = A.orig_index[j];
-        const uint32_t gi = event_index(A, j);
-        if (w[1] >= A.n_in) { push_event(ev, ABFT_EV_ROW_SIZE, gi, 0, FMT_COO); valid = false; }
-        else if (w[0] >= A.n_out) { push_event(ev, ABFT_EV_COL_SIZE, gi, 0, FMT_COO); valid = false; }
-        else if (i + 1u < A.nnz) {
-          const uint4 nx = A.elems[A.pos_of_orig[i + 1u]];
-          if (w[1] > nx.y) { push_event(ev, ABFT_EV_ROW_ORDER, gi, 0, FMT_COO); valid = false; }
-          else if (w[1] == nx.y && w[0] >= nx.x) { push_event(ev, ABFT_EV_COL_ORDER, gi, 0, FMT_COO); valid = false; }
+      if (valid) {
+        const uint32_t ncol = nxt_cr[s].x, nrow = nxt_cr[s].y;
+        int kind = 0;
+        if (w[1] >= A.n_in) kind = ABFT_EV_ROW_SIZE;
+        else if (w[0] >= A.n_out) kind = ABFT_EV_COL_SIZE;
+        else if (has_nxt[s] && w[1] > nrow) kind = ABFT_EV_ROW_ORDER;
+        else if (has_nxt[s] && w[1] == nrow && w[0] >= ncol) kind = ABFT_EV_COL_ORDER;
+        if (__builtin_expect(kind != 0, 0)) {
+          push_event(ev, (uint32_t)kind, event_index(A, j), 0, FMT_COO);
+          valid = false;
         }
       }
     } else if (MODE >= MODE_SED) {
@@ -1258,12 +1286,6 @@ int spmv_sweep_blocks_per_cu(int mode, int rpt) {
 // the (repaired) stored words, merged by caller's index with the queued products.
 // Stored order inside a group is the caller's order in both layouts, so the merge is a
 // two-way merge.  A fused vec.result product is corrected through partial 0.
-// where output c's own elements sit: the one group (streaming layout), or its slice of
-// segment (group, panel rg) in the panel layout
-struct FixLayout {
-  int kind;  // 0 streaming, 1 panels
-  CsrPanels P;
-};
 __device__ __forceinline__ void fixup_range(const CooDev &A, const FixLayout &F, uint32_t c, uint32_t rg, uint32_t &lo,
                                             uint32_t &hi) {
   if (F.kind == 0) { lo = A.grp_ptr[c]; hi = A.grp_ptr[c + 1]; return; }
@@ -1274,20 +1296,21 @@ __device__ __forceinline__ void fixup_range(const CooDev &A, const FixLayout &F,
   hi = e0 + ptr[c % ABFT_PANEL_ROWS + 1];
 }
 
-template <int MODE>
-__global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, FixLayout F,
-                                                               const double *__restrict__ x, double *__restrict__ y,
-                                                               FuseOut fuse, bool fused) {
-  __shared__ double s_p[ABFT_BLOCK];
-  __shared__ uint32_t s_o[ABFT_BLOCK];
-  __shared__ uint32_t s_n[ABFT_BLOCK];
+// All threads of the calling workgroup (256 or 1024).  Runs behind every COO SpMV -- inside the
+// fold of its fused product when there is one, else as coo_fixup_kernel.
+__device__ void coo_fixup_body(const FixArgs &fx) {
+  __shared__ double s_p[1024];
+  __shared__ uint32_t s_o[1024];
+  __shared__ uint32_t s_n[1024];
+  const CooDev &A = fx.A;
+  const uint32_t NT = blockDim.x;
   uint32_t n = __hip_atomic_load(A.moved.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (n == 0u) return;  // uniform
   if (n > A.moved.cap) n = A.moved.cap;
   const MovedEntry *in = A.moved.buf;
   MovedEntry *srt = A.moved.buf + A.moved.cap;
   // rank sort by (column, caller's index); keys are distinct
-  for (uint32_t i = threadIdx.x; i < n; i += ABFT_BLOCK) {
+  for (uint32_t i = threadIdx.x; i < n; i += NT) {
     const MovedEntry e = in[i];
     uint32_t rank = 0;
     for (uint32_t k = 0; k < n; k++) {
@@ -1305,24 +1328,24 @@ __global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, FixLayo
     while (q1 < n && srt[q1].col == c) q1++;
     double sum = 0.0;   // thread 0 only
     uint32_t qi = q;    // thread 0 only
-    const uint32_t nranges = F.kind == 0 ? 1u : F.P.npanels;
+    const uint32_t nranges = fx.F.kind == 0 ? 1u : fx.F.P.npanels;
     for (uint32_t rg = 0; rg < nranges; rg++) {
       uint32_t lo, hi;
-      fixup_range(A, F, c, rg, lo, hi);
-      for (uint32_t base = lo; base < hi; base += ABFT_BLOCK) {
+      fixup_range(A, fx.F, c, rg, lo, hi);
+      for (uint32_t base = lo; base < hi; base += NT) {
         const uint32_t j = base + threadIdx.x;
         if (j < hi) {
           const uint4 e = A.elems[j];
-          const uint32_t col = MODE >= MODE_SED ? (e.x & ABFT_COLMASK) : e.x;
+          const uint32_t col = fx.ecc ? (e.x & ABFT_COLMASK) : e.x;
           const bool in_range = e.y < A.n_in;
-          const double xv = in_range ? x[e.y] : 0.0;
+          const double xv = in_range ? fx.x[e.y] : 0.0;
           s_p[threadIdx.x] = as_double(e.z, e.w) * xv;
           s_o[threadIdx.x] = A.orig_index[j];
           s_n[threadIdx.x] = col == c ? 1u : 0u;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-          const uint32_t cnt = min((uint32_t)ABFT_BLOCK, hi - base);
+          const uint32_t cnt = min(NT, hi - base);
           for (uint32_t k = 0; k < cnt; k++) {
             if (!s_n[k]) continue;  // moved out itself
             while (qi < q1 && srt[qi].orig < s_o[k]) sum += srt[qi++].prod;
@@ -1334,30 +1357,38 @@ __global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(CooDev A, FixLayo
     }
     if (threadIdx.x == 0) {
       while (qi < q1) sum += srt[qi++].prod;
-      const double old = y[c];
-      y[c] = sum;
-      if (fused) {
-        const double xo = x[fuse.x_off + c];
-        fuse.partials[0] += xo * sum - xo * old;
+      const double old = fx.y[c];
+      fx.y[c] = sum;
+      if (fx.partial0) {
+        const double xo = fx.x[fx.x_off + c];
+        *fx.partial0 += xo * sum - xo * old;
       }
     }
     q = q1;
   }
+  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(A.moved.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-hipError_t launch_coo_fixup(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, EventRing ev,
-                            const FuseOut *fuse, hipStream_t s) {
-  (void)ev;
-  if (!A.moved.buf || A.nnz == 0) return hipSuccess;
-  FixLayout F{};
-  F.kind = P ? 1 : 0;
-  if (P) F.P = *P;
-  const FuseOut f = fuse ? *fuse : FuseOut{};
-#define ABFT_FIX(M) hipLaunchKernelGGL(coo_fixup_kernel<M>, dim3(1), dim3(ABFT_BLOCK), 0, s, A, F, x, y, f, fuse != nullptr)
-  if (mode >= MODE_SED) ABFT_FIX(MODE_SED); else ABFT_FIX(MODE_NONE);
-#undef ABFT_FIX
+__global__ __launch_bounds__(ABFT_BLOCK) void coo_fixup_kernel(FixArgs fx) { coo_fixup_body(fx); }
+
+FixArgs make_fix_args(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, const FuseOut *fuse) {
+  FixArgs fx{};
+  fx.A = A;
+  fx.F.kind = P ? 1 : 0;
+  if (P) fx.F.P = *P;
+  fx.x = x; fx.y = y;
+  fx.partial0 = fuse ? fuse->partials : nullptr;
+  fx.x_off = fuse ? fuse->x_off : 0u;
+  fx.ecc = mode >= MODE_SED;
+  fx.on = A.moved.buf && A.nnz ? 1 : 0;
+  return fx;
+}
+
+hipError_t launch_coo_fixup(const FixArgs &fx, hipStream_t s) {
+  if (!fx.on) return hipSuccess;
+  hipLaunchKernelGGL(coo_fixup_kernel, dim3(1), dim3(ABFT_BLOCK), 0, s, fx);
   return hipGetLastError();
 }
 
@@ -1466,8 +1497,9 @@ __device__ __forceinline__ void reduce_finish(double block_value, const ReduceOu
 // workgroup adds a contiguous chunk in a fixed order, then the chunks' sums meet
 // through the same last-arriver protocol as every other reduction.
 __global__ __launch_bounds__(ABFT_BLOCK) void fold_partials_kernel(const double *__restrict__ parts, uint32_t n,
-                                                                   uint32_t chunk, ReduceOut out) {
+                                                                   uint32_t chunk, ReduceOut out, FixArgs fx) {
   __shared__ double s_w[4];
+  if (fx.on && blockIdx.x == 0) coo_fixup_body(fx);  // workgroup 0 owns partial 0, which the fix-up corrects
   const uint32_t lo = blockIdx.x * chunk, hi = min(n, lo + chunk);
   double acc = 0.0;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += 4u * ABFT_BLOCK) {
@@ -1483,15 +1515,18 @@ __global__ __launch_bounds__(ABFT_BLOCK) void fold_partials_kernel(const double 
   reduce_finish(acc, out, s_w);
 }
 
-hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, const ReduceOut &big, hipStream_t s) {
+hipError_t launch_fuse_finalize(const FuseOut &f, uint32_t nblk, const ReduceOut &big, const FixArgs *fix,
+                                hipStream_t s) {
+  FixArgs fx{};
+  if (fix) fx = *fix;
   if (nblk <= 8192u || !big.partials) {
-    hipLaunchKernelGGL(fuse_finalize_kernel, dim3(1), dim3(1024), 0, s, f, nblk);
+    hipLaunchKernelGGL(fuse_finalize_kernel, dim3(1), dim3(1024), 0, s, f, nblk, fx);
     return hipGetLastError();
   }
   uint32_t nb = (nblk + 2047u) / 2048u;
   if (nb > 64u) nb = 64u;
   const uint32_t chunk = (nblk + nb - 1u) / nb;
-  hipLaunchKernelGGL(fold_partials_kernel, dim3(nb), dim3(ABFT_BLOCK), 0, s, f.partials, nblk, chunk, big);
+  hipLaunchKernelGGL(fold_partials_kernel, dim3(nb), dim3(ABFT_BLOCK), 0, s, f.partials, nblk, chunk, big, fx);
   return hipGetLastError();
 }
 

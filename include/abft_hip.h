@@ -245,6 +245,19 @@ int abft_hip_spmv_part(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
 int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                                abft_hip_vector *result, int vec_offset, double *dev_result, int part);
 
+/* SpMV by ranges of column panels, for a shard whose input vector arrives slot by slot (an
+ * exchange pipelined with the multiplication).  A matrix in the sweep layout is stored in
+ * *npanels panels of *width input entries each (abft_hip_matrix_panels; any other layout:
+ * one panel) and its rows are summed panel by panel in ascending order, so
+ *   spmv_dot_range_dev(.., 0, k), spmv_dot_range_dev(.., k, npanels)
+ * on unchanged vectors equal one abft_hip_spmv_dot_dev bit for bit: the first range starts
+ * the row sums, a later one continues from what `result` holds, the one that ends at
+ * npanels completes the fused product in dev_result (NULL: plain SpMV).  Panels [c0, c1)
+ * read input entries [c0 * width, c1 * width) only. */
+int abft_hip_matrix_panels(abft_hip_matrix *mat, int *npanels, int *width);
+int abft_hip_spmv_dot_range_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                                abft_hip_vector *result, int vec_offset, double *dev_result, int c0, int c1);
+
 /* ---- graph replay ------------------------------------------------------ */
 
 /* Capture everything enqueued on the context's stream between begin and end -- the

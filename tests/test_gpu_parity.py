@@ -581,6 +581,48 @@ def test_coo_silently_corrupted_column_scatters_like_reference(amd, mode, layout
     assert compared >= 6 and moved >= 5, (compared, moved)
 
 
+@pytest.mark.parametrize("mode", ["none", "secded"])
+def test_spmv_by_panel_ranges_equals_one_launch(amd, mode, monkeypatch):
+    """abft_hip_spmv_dot_range_dev: the panel sweep cut into ranges (a shard whose input vector
+    arrives slot by slot) -- the ranges in ascending order equal one launch bit for bit, y and
+    the fused product; the second range only reads its own part of the input vector."""
+    import ctypes as C
+    from abft_sparse_cg_amd import capi
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep")
+    monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", "64")
+    cols, rows, vals, n = MATS["rnd300"]()
+    x = rhs(n, 4)
+    seen = []
+    ctx = amd.HIPContext(mode, "csr", on_event=lambda ev, fatal: seen.extend(ev))
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        if mode == "secded":
+            ctx.inject_at(A, 5, [17])
+        L, h = ctx.L, ctx.h
+        npan, width = C.c_int(0), C.c_int(0)
+        capi.check(L.abft_hip_matrix_panels(A.h, C.byref(npan), C.byref(width)))
+        assert (npan.value, width.value) == ((n + 63) // 64, 64)
+        vx, vy, sc = ctx.create_vector(n), ctx.create_vector(n), ctx.create_vector(2)
+        ctx.upload(vx, x)
+        capi.check(L.abft_hip_spmv_dot_dev(h, A.h, vx.h, vy.h, 0, sc.device_ptr))
+        y0, s0 = ctx.download(vy), ctx.download(sc)
+        ctx._drain()
+        cut = npan.value // 2
+        xa = x.copy()
+        xa[cut * 64:] = np.nan  # not there yet while the first range runs
+        ctx.upload(vx, xa)
+        ctx.upload(vy, np.full(n, np.nan))
+        capi.check(L.abft_hip_spmv_dot_range_dev(h, A.h, vx.h, vy.h, 0, sc.device_ptr, 0, cut))
+        ctx.upload(vx, x)
+        capi.check(L.abft_hip_spmv_dot_range_dev(h, A.h, vx.h, vy.h, 0, sc.device_ptr, cut, npan.value))
+        y1, s1 = ctx.download(vy), ctx.download(sc)
+        assert bits_equal(y0, y1) and s0[0] == s1[0]
+        assert bits_equal(y0, OracleMatrix(CSR, mode, cols, rows, vals, n).spmv(x))
+    finally:
+        ctx.close()
+    assert seen == ([(2, 5, 17)] if mode == "secded" else [])
+
+
 @pytest.mark.parametrize("mat,lo,hi", [("lap40", 40, 1280), ("ragged", 7, 650), ("lap40", 0, 1320), ("rnd300", 100, 100)])
 @pytest.mark.parametrize("mode", ["none", "secded"])
 def test_spmv_in_two_parts_equals_one_launch(amd, mode, mat, lo, hi):
