@@ -60,6 +60,7 @@ SIGNATURES = {
     "abft_hip_matrix_read_csr": (C.c_int, [vp, vp, vp, vp]),
     "abft_hip_matrix_read_coo": (C.c_int, [vp, vp]),
     "abft_hip_inject": (C.c_int, [vp, C.c_uint32, i32p, C.c_int]),
+    "abft_hip_inject_rowptr": (C.c_int, [vp, C.c_uint32, C.c_uint32]),
     "abft_hip_vector_create": (C.c_int, [vp, C.c_int, vpp]),
     "abft_hip_vector_view": (C.c_int, [vp, C.c_int, C.c_int, vpp]),
     "abft_hip_vector_destroy": (C.c_int, [vp]),

@@ -936,6 +936,24 @@ extern "C" int abft_hip_inject(abft_hip_matrix *mat, uint32_t index, const int *
   return ABFT_OK;
 }
 
+// The row-pointer array is matrix data too, and constraints mode checks it (reference
+// CSR/CPUContext.cpp:173-182), but the reference's inject_bitflip never reaches it: this
+// additive entry XORs `mask` into rowptr[row] so that those two checks can be exercised.
+extern "C" int abft_hip_inject_rowptr(abft_hip_matrix *mat, uint32_t row, uint32_t mask) {
+  if (!mat || mat->fmt != ABFT_FMT_CSR) return set_err(ABFT_ERR_INVALID, "not a CSR matrix");
+  if (int rc = bind(mat->ctx)) return rc;
+  if (row > mat->csr.n_out) return set_err(ABFT_ERR_INVALID, "row pointer %u outside [0,%u]", row, mat->csr.n_out);
+  hipStream_t s = mat->ctx->stream;
+  uint32_t v = 0;
+  uint32_t *p = const_cast<uint32_t *>(mat->csr.rowptr) + row;
+  HIPCHK(hipMemcpyAsync(&v, p, sizeof(v), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  v ^= mask;
+  HIPCHK(hipMemcpyAsync(p, &v, sizeof(v), hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return ABFT_OK;
+}
+
 // ------------------------------------------------------------------ vectors --
 
 extern "C" int abft_hip_vector_create(abft_hip_ctx *ctx, int N, abft_hip_vector **vec) {
@@ -1451,9 +1469,21 @@ extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap
   HIPCHK(hipMemsetAsync(ctx->ring.count, 0, sizeof(uint32_t), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   ctx->host_slot->evcount = 0;
-  std::sort(ev.begin(), ev.end(), [](const abft_event &a, const abft_event &b) {
+  // The order a single-threaded reference run meets them in.  ECC events and the COO
+  // constraint checks: by element index.  The CSR constraint checks are made row by row --
+  // a row's two row-pointer checks, then its elements in order (CSR/CPUContext.cpp:173-200) --
+  // and their events arrive with that row in `bit` (cleared again below).
+  auto csr_check = [](const abft_event &e) { return e.fmt == ABFT_FMT_CSR && e.kind >= ABFT_EV_ROW_SIZE; };
+  std::sort(ev.begin(), ev.end(), [&](const abft_event &a, const abft_event &b) {
+    if (csr_check(a) && csr_check(b)) {
+      if (a.bit != b.bit) return a.bit < b.bit;
+      const bool ea = a.kind >= ABFT_EV_COL_SIZE, eb = b.kind >= ABFT_EV_COL_SIZE;
+      if (ea != eb) return !ea;
+    }
     return a.index != b.index ? a.index < b.index : a.kind < b.kind;
   });
+  for (abft_event &e : ev)
+    if (csr_check(e)) e.bit = 0;
   // the reference stops at its first fatal line: look at ALL queued events for it, then
   // hand over what precedes it (a short caller buffer must not hide a fatal event)
   uint32_t want = n;

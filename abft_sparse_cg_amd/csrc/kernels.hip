@@ -386,7 +386,7 @@ template <int MODE>
 __device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev, uint32_t base,
                                             uint32_t rs, uint32_t re, uint32_t row_end,
                                             const double *s_prod, const uint32_t *s_col,
-                                            double &acc) {
+                                            double &acc, uint32_t row = 0) {
   if (MODE != MODE_CONSTRAINTS) {
     // four LDS reads in flight, then up to four adds in element order; a lane
     // past its row's end re-reads its last slot and skips the add (no "+ 0.0":
@@ -406,14 +406,14 @@ __device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev
     const uint32_t k = i - base;
     const uint32_t col = s_col[k];
     if (col >= A.n_in) {
-      push_event(ev, ABFT_EV_COL_SIZE, A.index_base + i, 0, FMT_CSR);
+      push_event(ev, ABFT_EV_COL_SIZE, A.index_base + i, row, FMT_CSR);  // `bit` = row: the drain's sort key
       return false;
     }
     if (i + 1u < row_end) {
       // the next column is in the tile unless this is the last staged element
       const uint32_t nxt = (i + 1u < re) ? s_col[k + 1u] : A.cols[i + 1u];
       if (nxt <= col) {
-        push_event(ev, ABFT_EV_COL_ORDER, A.index_base + i, 0, FMT_CSR);
+        push_event(ev, ABFT_EV_COL_ORDER, A.index_base + i, row, FMT_CSR);
         return false;
       }
     }
@@ -469,12 +469,12 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
         if (FUSE) xr = x[fuse.x_off + row];
       }
       if (MODE == MODE_CONSTRAINTS) {  // reference CSR/CPUContext.cpp:173-182
-        if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
-        if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
+        if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, row, FMT_CSR); continue; }
+        if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, row, FMT_CSR); continue; }
       }
       if (rs < e0 || re > e1 || re < rs) continue;  // inconsistent row pointers: never touch LDS out of range
       double acc = 0.0;
-      if (csr_row_sum<MODE>(A, ev, base, rs, re, re, s_prod, s_col, acc)) {
+      if (csr_row_sum<MODE>(A, ev, base, rs, re, re, s_prod, s_col, acc, row)) {
         y[row] = acc;
         if (FUSE) dsum += xr * acc;
       }
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
     for (uint32_t row = row0; row < row1; row++) {
       const uint32_t rs = A.rowptr[row], re = A.rowptr[row + 1];
       if (MODE == MODE_CONSTRAINTS) {
-        if (re > A.nnz) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_SIZE, row, 0, FMT_CSR); continue; }
-        if (re < rs) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_ORDER, row, 0, FMT_CSR); continue; }
+        if (re > A.nnz) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_SIZE, row, row, FMT_CSR); continue; }
+        if (re < rs) { if (threadIdx.x == 0) push_event(ev, ABFT_EV_ROW_ORDER, row, row, FMT_CSR); continue; }
       }
       if (re > A.nnz || re < rs) continue;
       double acc = 0.0;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_kernel(CsrDev A, const do
         __syncthreads();
         csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
         __syncthreads();
-        if (threadIdx.x == 0 && ok) ok = csr_row_sum<MODE>(A, ev, b, lo, hi, re, s_prod, s_col, acc);
+        if (threadIdx.x == 0 && ok) ok = csr_row_sum<MODE>(A, ev, b, lo, hi, re, s_prod, s_col, acc, row);
         lo = hi;
       }
       if (threadIdx.x == 0 && ok) {

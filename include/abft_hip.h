@@ -146,6 +146,10 @@ int abft_hip_matrix_read_coo(abft_hip_matrix *mat, void *elements);
  * 32-63 row, 64-127 value. */
 int abft_hip_inject(abft_hip_matrix *mat, uint32_t index, const int *bits, int nbits);
 
+/* XOR `mask` into row pointer `row` (0..N) of a CSR matrix: the array constraints mode checks
+ * at reference CSR/CPUContext.cpp:173-182 and the reference's own injector never touches. */
+int abft_hip_inject_rowptr(abft_hip_matrix *mat, uint32_t row, uint32_t mask);
+
 /* ---- vectors ----------------------------------------------------------- */
 
 /* reference CSR/CPUContext.cpp:54-75: contents are uninitialised */

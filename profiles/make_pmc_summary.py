@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01/pmc_*.json (separate rocprofv3 --pmc passes, condensed by summarize.py)
+"""profiles/r02/pmc_*.json (separate rocprofv3 --pmc passes, condensed by summarize.py)
 -> profiles/pmc_summary.json: HBM bytes per SpMV, which bench.py reports as
 roofline.traffic.
 
@@ -16,10 +16,13 @@ import json
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-R = os.path.join(HERE, "r01")
+R = os.path.join(HERE, "r02")
 CASES = {  # tag -> (workload key used by bench.py, bench line of the traced run)
-    "laplace_none": ("laplace5:3162,3162/csr/none", "bench_under_trace.json"),
+    "laplace_none": ("laplace5:3162,3162/csr/none", "bench_under_trace_laplace_none.json"),
+    "laplace_sed": ("laplace5:3162,3162/csr/sed", "bench_under_trace_laplace_sed.json"),
+    "laplace_secded": ("laplace5:3162,3162/csr/secded", "bench_under_trace_laplace_secded.json"),
     "random_secded": ("random:4194304,24,1/csr/secded", "bench_under_trace_random_secded.json"),
+    "powerlaw_coo_sec7": ("powerlaw:2097152,2/coo/sec7", "bench_under_trace_powerlaw_coo_sec7.json"),
 }
 
 
@@ -38,7 +41,7 @@ def main():
         f, w, t = (load("pmc_%s_%s.json" % (c, tag)) for c in ("fetch_size", "write_size", "tcc_hit_sum"))
         n = json.load(open(os.path.join(R, benchfile)))["config"]["N"]
         sps = [k for k in f if "spmv" in k]  # the panel layout runs two instantiations (with / without the fused dot)
-        fold = pick(f, "fuse_finalize")
+        fold = pick(f, "fuse_finalize") or pick(f, "fold_partials")
         n_spmv = max(f[fold]["FETCH_SIZE"]["launches"], 1) if fold else f[sps[0]]["FETCH_SIZE"]["launches"]
 
         def per_spmv_total(d, counter):

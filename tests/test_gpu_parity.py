@@ -213,6 +213,35 @@ def test_constraints_mode_detects_like_reference(amd, fmt):
     assert fatal_seen > 20
 
 
+def test_constraints_mode_row_pointer_checks(amd):
+    """The two checks no element flip reaches (reference CSR/CPUContext.cpp:173-182: "row size" when
+    a row's end lies past nnz, "row order" when it lies before its start): a bit of a row pointer
+    flipped on both sides -- same first fatal event as the oracle's run over the same arrays."""
+    from abft_sparse_cg_amd import capi
+    cols, rows, vals, n = random_spd(120, 6, seed=8)
+    x = rhs(n, 5)
+    kinds = set()
+    for row, mask in ((7, 1 << 30), (7, 1 << 3), (1, 1 << 5), (n, 1 << 29), (60, 1 << 9), (119, 1 << 1), (33, 1 << 4)):
+        o = OracleMatrix(CSR, "constraints", cols, rows, vals, n)
+        o._view("ora_matrix_csr_rowptr", np.uint32, n + 1)[row] ^= np.uint32(mask)
+        h = Hip(amd, CSR, "constraints", cols, rows, vals, n)
+        try:
+            capi.check(h.ctx.L.abft_hip_inject_rowptr(h.A.h, row, mask))
+            assert np.array_equal(h.ctx.rowptr(h.A), o.csr_arrays()[1])
+            h.spmv(x)
+            o.spmv(x)
+            ev, fatal = h.take_events()
+            oev, ofatal = o.events()
+            assert fatal == ofatal, (row, mask)
+            if fatal:
+                assert ev[:1] == oev[:1], (row, mask, ev, oev)
+                assert event_lines(ev[:1], CSR) == event_lines(oev[:1], CSR)
+                kinds.add(ev[0][0])
+        finally:
+            h.close()
+    assert {5, 6} <= kinds  # ABFT_EV_ROW_SIZE and ABFT_EV_ROW_ORDER both seen
+
+
 def test_shard_geometry_and_global_event_index(amd):
     """Row-block shard: n_out local rows, columns index a longer vector, events
     carry index_base + local element index."""
