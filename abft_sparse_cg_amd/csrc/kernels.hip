@@ -1083,15 +1083,22 @@ __device__ __forceinline__ uint32_t board_min(const BoardView &v) {
 // (CSR/CPUContext.cpp:115-133 and variants).  RPT rows per thread: 256 * RPT rows per
 // workgroup, chosen at create time so that all groups are resident at once.
 template <int MODE, int RPT>
-__global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
+__global__ __launch_bounds__(ABFT_BLOCK, RPT >= 8 ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
                                                                 const double *__restrict__ x, double *__restrict__ y,
                                                                 EventRing ev, FuseOut fuse, bool fused, uint32_t c0,
                                                                 uint32_t c1) {
   constexpr int EPT = RPT <= 4 ? 4 : ABFT_CFG_SWEEP_EPT;  // small groups have small segments: smaller tiles
   constexpr uint32_t TILE = ABFT_BLOCK * EPT, GROUP = 256u * RPT;
-  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  // the next tile's streaming loads issued behind this tile's gathers, one tile ahead in registers
+  constexpr bool PF = (ABFT_CFG_SWEEP_PREFETCH >> (RPT == 16 ? 1 : 0)) & 1;
+  // two product buffers: a wave that has summed tile t goes straight on to stage tile t + 1 into
+  // the other buffer -- one workgroup barrier per tile (behind the staging) instead of two, and the
+  // waves of a workgroup may be a phase apart (everyone has left tile t - 1's sums, which read the
+  // buffer now being written, before anyone passed tile t's barrier)
+  __shared__ __attribute__((aligned(16))) double s_buf[2][TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
   __shared__ uint32_t s_last;
+  uint32_t par = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t nsteps = c1 - c0;
@@ -1127,6 +1134,8 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
       acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
     }
     const uint32_t *wb = L.wbase + 4u * (size_t)g * L.npanels;
+    CsrTileRegs<EPT> tr_cur, tr_nxt;
+    uint32_t pf_base = 0xffffffffu;  // PF: base of the tile whose loads are in tr_cur
     for (uint32_t c = c0; c < c1; c++) {
       const uint32_t step = round * nsteps + (c - c0);
       const uint32_t e0 = wb[4u * c], e1 = wb[4u * c + 4u];
@@ -1176,8 +1185,25 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
         for (uint32_t lo = e0; lo < e1;) {
           const uint32_t b = lo & ~1u;
           const uint32_t hi = min(e1, b + TILE);
-          __syncthreads();
-          csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+          double *s_prod = s_buf[par];
+          par ^= 1u;
+          if (PF) {
+            if (pf_base != b) csr_issue_loads<EPT>(A, b, hi, tr_cur);  // nothing ahead yet: the group's first tile
+            // the tile after this one: the rest of the segment, or the head of the next non-empty one
+            uint32_t nlo = hi, ne1 = e1;
+            bool more = hi < e1;
+            if (!more)
+              for (uint32_t cn = c + 1u; cn < c1 && !more; cn++) {
+                nlo = wb[4u * cn]; ne1 = wb[4u * cn + 4u];
+                more = nlo != ne1;
+              }
+            const uint32_t nb = more ? (nlo & ~1u) : b, nhi = more ? min(ne1, nb + TILE) : b;
+            csr_consume<MODE, EPT>(A, x, ev, b, lo, hi, tr_cur, s_prod, s_col, true, nb, nhi, tr_nxt);
+            tr_cur = tr_nxt;
+            pf_base = more ? nb : 0xffffffffu;
+          } else {
+            csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
+          }
           __syncthreads();
 #ifdef ABFT_DBG_NOPHASE2  // timing-only build: wrong results
           if (threadIdx.x == 1023u)
