@@ -445,10 +445,20 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
   if ((env && strcmp(env, "sweep") && strcmp(env, "auto")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0)
     return false;
   if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
-  // rows per thread: the smallest group size whose groups are all resident at once
-  sb.rpt = 16;
-  for (int rpt : {2, 4, 8})
-    if (((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt) <= capacity(rpt)) { sb.rpt = rpt; break; }
+  // rows per thread: the group size that keeps the most workgroups per CU busy (up to 4: more did
+  // not help), then the fewest rounds, then the smallest groups
+  {
+    double best = -1.0;
+    uint64_t best_rounds = 0;
+    for (int rpt : {2, 4, 8, 16}) {
+      const uint64_t groups = ((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt), cap = std::max<uint64_t>(capacity(rpt), 1);
+      const uint64_t rounds = (groups + cap - 1) / cap;
+      const double per_cu = std::min(4.0, (double)((groups + rounds - 1) / rounds) / 256.0);
+      if (per_cu > best + 1e-9 || (per_cu > best - 1e-9 && rounds < best_rounds)) {
+        best = per_cu; best_rounds = rounds; sb.rpt = rpt;
+      }
+    }
+  }
   if (const char *r = getenv("ABFT_HIP_SWEEP_RPT")) {
     const int v = atoi(r);
     if (v == 2 || v == 4 || v == 8 || v == 16) sb.rpt = v;

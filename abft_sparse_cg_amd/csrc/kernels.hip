@@ -1083,7 +1083,7 @@ __device__ __forceinline__ uint32_t board_min(const BoardView &v) {
 // (CSR/CPUContext.cpp:115-133 and variants).  RPT rows per thread: 256 * RPT rows per
 // workgroup, chosen at create time so that all groups are resident at once.
 template <int MODE, int RPT>
-__global__ __launch_bounds__(ABFT_BLOCK, RPT >= 8 ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
+__global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
                                                                 const double *__restrict__ x, double *__restrict__ y,
                                                                 EventRing ev, FuseOut fuse, bool fused, uint32_t c0,
                                                                 uint32_t c1) {
@@ -1095,7 +1095,10 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT >= 8 ? 4 : 5) void spmv_sweep_kerne
   // the other buffer -- one workgroup barrier per tile (behind the staging) instead of two, and the
   // waves of a workgroup may be a phase apart (everyone has left tile t - 1's sums, which read the
   // buffer now being written, before anyone passed tile t's barrier)
-  __shared__ __attribute__((aligned(16))) double s_buf[2][TILE];
+  // (where 5 workgroups per CU are wanted -- every RPT but 16 -- two 16 KB buffers would not fit
+  // beside each other five times: one buffer, two barriers)
+  constexpr bool TWO = RPT == 16 || EPT <= 4;
+  __shared__ __attribute__((aligned(16))) double s_buf[TWO ? 2 : 1][TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
   __shared__ uint32_t s_last;
   uint32_t par = 0;
@@ -1185,8 +1188,9 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT >= 8 ? 4 : 5) void spmv_sweep_kerne
         for (uint32_t lo = e0; lo < e1;) {
           const uint32_t b = lo & ~1u;
           const uint32_t hi = min(e1, b + TILE);
-          double *s_prod = s_buf[par];
+          double *s_prod = s_buf[TWO ? par : 0u];
           par ^= 1u;
+          if (!TWO) __syncthreads();
           if (PF) {
             if (pf_base != b) csr_issue_loads<EPT>(A, b, hi, tr_cur);  // nothing ahead yet: the group's first tile
             // the tile after this one: the rest of the segment, or the head of the next non-empty one
