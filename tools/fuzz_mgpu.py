@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""The C++ driver split over several processes (host/mgpu-run --one-gpu: every rank on GPU 0,
-collectives staged through the host) against the same executable in one process, on random
-Matrix-Market inputs: same iteration count, rr lines, ECC event lines (global indices) and
-error report.  Exercises the partition logic on awkward shapes: few rows per rank, empty
+"""The C++ drivers (cg-csr cut by row blocks, cg-coo by column blocks) split over several
+processes (host/mgpu-run --one-gpu: every rank on GPU 0, collectives staged through the host)
+against the same executable in one process, on random Matrix-Market inputs: same iteration
+count, rr lines, ECC event lines (global indices) and error report.  Exercises the partition logic on awkward shapes: few rows per rank, empty
 rows at block boundaries, dense and diagonal-only matrices.
 
     python tools/fuzz_mgpu.py [cases] [first_seed]"""
@@ -58,13 +58,17 @@ def main():
             n, nnz = write_mtx(path, rng)
             world = int(rng.choice([2, 3, 4]))
             mode = str(rng.choice(["none", "sed", "sec7", "sec8", "secded", "constraints"]))
-            args = ["-f", path, "-t", "hip", "-m", mode, "-b", str(int(rng.choice([1, 1, 3])))]
+            fmt = str(rng.choice(["csr", "coo"]))
+            blocks = int(rng.choice([1, 1, 3]))
+            args = ["-f", path, "-t", "hip", "-m", mode, "-b", str(blocks)]
             if mode not in ("none", "constraints") and rng.random() < 0.6:
-                args += ["--flip-at", "%d:%d" % (int(rng.integers(0, nnz)), int(rng.integers(0, 96)))]
-            one = subprocess.run([os.path.join(HOST, "cg-csr")] + args, capture_output=True, text=True, timeout=120)
-            many = subprocess.run([os.path.join(HOST, "mgpu-run"), str(world), "--one-gpu", "--",
-                                   os.path.join(HOST, "cg-csr")] + args, capture_output=True, text=True, timeout=300)
-            what = "seed %d: n=%d nnz=%d world=%d %s" % (seed + k, n, nnz, world, " ".join(args[4:]))
+                # (single flips in the ECC modes: detected or corrected on whichever rank holds the element)
+                args += ["--flip-at", "%d:%d" % (int(rng.integers(0, nnz * blocks)), int(rng.integers(0, 96 if fmt == "csr" else 128)))]
+            exe = os.path.join(HOST, "cg-" + fmt)
+            one = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+            many = subprocess.run([os.path.join(HOST, "mgpu-run"), str(world), "--one-gpu", "--", exe] + args,
+                                  capture_output=True, text=True, timeout=300)
+            what = "seed %d: %s n=%d nnz=%d world=%d %s" % (seed + k, fmt, n, nnz, world, " ".join(args[4:]))
             if n * int(args[args.index("-b") + 1]) < world:
                 ok = many.returncode == 2 and "ranks for a matrix" in many.stderr  # refused, loudly
             else:
