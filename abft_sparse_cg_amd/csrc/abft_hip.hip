@@ -790,7 +790,12 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
   if (m->use_panels) {
     const int per_cu = format == ABFT_FMT_CSR ? spmv_csr_panels_blocks_per_cu(mode, true) : 8;
     m->panel_grid = std::min<uint32_t>(m->panels.ngroups, (uint32_t)(per_cu * ctx->num_cus));
-    m->panel_chunk = 2;  // panels per launch: the kernel boundary keeps the chip in one 4 MB window of x
+    // panels per launch: the kernel boundary keeps the chip in one window of x -- 4 MB (config 4's
+    // 33 MB vector: 2 panels per launch were best), 8 MB where the whole vector is only a few L2s
+    // large and its misses come out of the Infinity Cache anyway (config 5, 16.8 MB: 223 us with 2
+    // panels per launch, 207 with 4, 210 with all 8 in one launch)
+    const uint32_t n_in_b = (format == ABFT_FMT_CSR ? m->csr.n_in : m->coo.n_in);
+    m->panel_chunk = (size_t)n_in_b * sizeof(double) <= ((size_t)24 << 20) ? 4 : 2;
     if (const char *e = getenv("ABFT_HIP_PANEL_CHUNK")) m->panel_chunk = (uint32_t)std::max(0L, atol(e));
     if (m->panel_chunk) m->panel_grid = m->panels.ngroups;  // one row group per workgroup between boundaries
   }

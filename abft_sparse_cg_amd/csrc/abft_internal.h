@@ -119,6 +119,9 @@ struct CooDev {
 #ifndef ABFT_CFG_SWEEP_EPT
 #define ABFT_CFG_SWEEP_EPT 8  // CSR elements per thread per tile of the sweep kernel
 #endif
+#ifndef ABFT_CFG_COO_PANEL_EPT
+#define ABFT_CFG_COO_PANEL_EPT 4  // 16-byte elements per thread per tile of the COO panel kernel
+#endif
 #ifndef ABFT_CFG_SWEEP_PREFETCH
 #define ABFT_CFG_SWEEP_PREFETCH 0  // bit 0: 8 rows per thread, bit 1: 16 (see spmv_sweep_kernel)
 #endif

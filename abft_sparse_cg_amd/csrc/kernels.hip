@@ -954,10 +954,10 @@ static hipError_t launch_coo_panels_mode(const CooDev &A, const CsrPanels &P, co
                                          EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0,
                                          uint32_t c1, hipStream_t s) {
   if (fuse)
-    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_COO_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
+    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
                        P, x, y, ev, *fuse, c0, c1);
   else
-    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_COO_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
+    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
                        P, x, y, ev, FuseOut{}, c0, c1);
   return hipGetLastError();
 }
@@ -1121,7 +1121,7 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
   }
   double dsum = 0.0;
   BoardView seen{~0ull, ~0ull};    // wave 0: the board as loaded one step ago
-  bool have_seen = false;
+  bool have_seen = false, gave_up = false;
   uint32_t dbg_spins = 0, dbg_waits = 0;
   for (uint32_t round = 0; round < nrounds; round++) {
     const uint32_t g = blockIdx.x + round * gridDim.x;
@@ -1170,16 +1170,20 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
           // completed step - lag + 1 steps (all of them then sit within `lag` panels).  The
           // board was loaded one step ago -- that load's latency ran beside the step's work --
           // and only a minimum still short then sends this wave polling (bounded).
-          if (step >= L.lag) {
+          if (step >= L.lag && !gave_up) {
             const uint32_t need = step + 1u - L.lag;
             uint32_t m = have_seen ? board_min(seen) : 0u;
             if (m < need) {
               dbg_waits++;
-              for (int it = 0; it < 8192 && m < need; it++) {
+              int it = 0;
+              for (; it < 1024 && m < need; it++) {
                 __builtin_amdgcn_s_sleep(4);
                 m = board_min(board_load(board, lane));
                 dbg_spins++;
               }
+              // ~1 ms and still short: a workgroup of this XCD is not running (CUs taken by another
+              // stream's kernels?) -- stop pacing for the rest of this launch rather than stall again
+              if (it == 1024) gave_up = true;
             }
           }
           seen = board_load(board, lane);
