@@ -162,6 +162,7 @@ def test_config4_random_csr_secded_full_size(amd, gen):
     x = np.random.default_rng(6).standard_normal(n)
     r = Run(amd, "csr", "secded", mat)
     try:
+        assert r.ctx.matrix_info(r.A) == ("sweep", 1)  # scattered columns over a 33 MB vector: one persistent launch
         y = r.spmv(x)
         # strictly diagonally dominant rows: A.1 = 1 + (rounding of the row sum), checked in exact order on sample rows
         for row in (0, 17, n // 2, n - 1):
@@ -230,3 +231,35 @@ def test_panel_layout_on_config2_matches_streaming_layout(amd, gen, monkeypatch)
         assert bits_equal(pan.spmv(x), y0) and pan.events == [(2, 31415926, 9)]
     finally:
         pan.close()
+
+
+@pytest.mark.parametrize("spec,rpt", [("random:4194304,24,1", "2"), ("random:4194304,24,1", "16"), (LAP, "16"), (LAP, "8")])
+def test_sweep_layout_full_size_matches_streaming_layout(amd, gen, monkeypatch, spec, rpt):
+    """The sweep layout at full size against the streaming layout of the same matrix, every row bit
+    for bit, the fused p.w to reduction tolerance, a flip reported with the caller's index: config 4
+    with the smallest and the largest group size (8 192 groups in several rounds / 1 024 in one),
+    and forced onto config 2's 10 M rows (2 442 or 4 883 groups: more than are resident at once)."""
+    mat = gen.generate(spec)
+    cols, rows, vals, n = mat
+    x = np.random.default_rng(9).standard_normal(n)
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "stream")
+    ref = Run(amd, "csr", "sec7", mat)
+    try:
+        y0 = ref.spmv(x)
+        d0 = ref.ctx.dot(ref.vx, ref.vy)
+    finally:
+        ref.close()
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep")
+    monkeypatch.setenv("ABFT_HIP_SWEEP_RPT", rpt)
+    sw = Run(amd, "csr", "sec7", mat)
+    try:
+        assert sw.ctx.matrix_info(sw.A)[0] == "sweep"
+        y1 = sw.spmv(x)
+        d1 = sw.ctx.dot(sw.vx, sw.vy)
+        assert bits_equal(y1, y0)
+        assert abs(d1 - d0) <= 1e-12 * float(np.abs(x * y0).sum())
+        sw.ctx.inject_at(sw.A, len(vals) // 3, [70])
+        assert bits_equal(sw.spmv(x), y0) and sw.events == [(2, len(vals) // 3, 70)]
+        assert bits_equal(sw.spmv(x), y0)  # again: the pacing board was reset by the last workgroup
+    finally:
+        sw.close()
