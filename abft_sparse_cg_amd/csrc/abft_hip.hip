@@ -308,10 +308,18 @@ static int dev_upload(abft_hip_matrix *m, T **dst, const T *src, size_t count, s
 static void matrix_free(abft_hip_matrix *m) {
   if (!m) return;
   if (m->use_sweep && m->sweep.debug) {
-    uint32_t d[4] = {0, 0, 0, 0};
-    if (hipMemcpy(d, m->sweep.debug, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess)
+    uint32_t d[16] = {0};
+    if (hipMemcpy(d, m->sweep.debug, sizeof(d), hipMemcpyDeviceToHost) == hipSuccess) {
       fprintf(stderr, "sweep pacing: %u workgroup exits, %u waits, %u unsuccessful polls (lag %u, %u panels, grid %u)\n",
               d[2], d[1], d[0], m->sweep.lag, m->sweep.npanels, m->sweep_grid);
+      unsigned long long t[6];
+      memcpy(t, d + 4, sizeof(t));
+      if (t[5])  // -DABFT_DBG_STAMPS builds: wave 0's clock per phase, as shares of a workgroup's life
+        fprintf(stderr, "sweep phases (%% of workgroup time): counts+scan %.1f, pacing %.1f, stage (loads, ECC, gathers, "
+                "LDS writes) %.1f, barrier %.1f, row sums %.1f, rest %.1f\n", 100.0 * t[0] / t[5], 100.0 * t[1] / t[5],
+                100.0 * t[2] / t[5], 100.0 * t[3] / t[5], 100.0 * t[4] / t[5],
+                100.0 * (t[5] - t[0] - t[1] - t[2] - t[3] - t[4]) / t[5]);
+    }
   }
   for (void *p : m->allocs) (void)hipFree(p);
   delete m;
@@ -563,8 +571,8 @@ static int finish_sweep(abft_hip_matrix *m, const SweepBuild &sb, uint32_t capac
   if (const char *e = getenv("ABFT_HIP_SWEEP_LAG")) m->sweep.lag = (uint32_t)std::max(0L, atol(e));
   if (getenv("ABFT_HIP_SWEEP_DEBUG")) {  // pacing statistics, printed when the matrix is destroyed
     uint32_t *d_dbg = nullptr;
-    const uint32_t z[4] = {0, 0, 0, 0};
-    if ((rc = dev_upload(m, &d_dbg, z, 4, 4))) return rc;
+    const uint32_t z[16] = {0};
+    if ((rc = dev_upload(m, &d_dbg, z, 16, 16))) return rc;
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     m->sweep.debug = d_dbg;
   }

@@ -1075,6 +1075,14 @@ __device__ __forceinline__ uint32_t board_min(const BoardView &v) {
   return min(min(r0, r1), min(r2, r3));
 }
 
+#ifdef ABFT_DBG_STAMPS  // timing build: where a workgroup's time goes (wave 0's clock), summed into L.debug[4..9]
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define STAMP_ADD(slot, a, b) dbg_t[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
+
 // Sweep-layout SpMV (CSR; see SweepLayout).  Stages a segment tile by tile through LDS with
 // the same branch-free load phase as the streaming kernel (ECC in registers, cold path out
 // of line); each thread then adds the staged products of its rows, in element order, onto
@@ -1123,6 +1131,10 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
   BoardView seen{~0ull, ~0ull};    // wave 0: the board as loaded one step ago
   bool have_seen = false, gave_up = false;
   uint32_t dbg_spins = 0, dbg_waits = 0;
+#ifdef ABFT_DBG_STAMPS
+  unsigned long long dbg_t[6] = {0, 0, 0, 0, 0, 0};
+  STAMP(t_begin);
+#endif
   for (uint32_t round = 0; round < nrounds; round++) {
     const uint32_t g = blockIdx.x + round * gridDim.x;
     if (g >= L.ngroups) {  // the last round may be short: nobody of this XCD has to wait for us
@@ -1143,6 +1155,7 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
       const uint32_t step = round * nsteps + (c - c0);
       const uint32_t e0 = wb[4u * c], e1 = wb[4u * c + 4u];
       if (e0 != e1) {  // uniform
+        STAMP(tA);
         // ---- this thread's RPT counts (one byte each) -> element ranges of its rows ----
         uint32_t cw[RPT >= 4 ? RPT / 4 : 1];
         {
@@ -1165,6 +1178,8 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
           start[2 * m + 1] = run + (inc >> 16) - b1;
           run += tot >> 16;
         }
+        STAMP(tB);
+        STAMP_ADD(0, tA, tB);
         if (pace && wave == 0u) {
           // before gathering from panel `step`: the slowest workgroup of this XCD must have
           // completed step - lag + 1 steps (all of them then sit within `lag` panels).  The
@@ -1189,7 +1204,10 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
           seen = board_load(board, lane);
           have_seen = true;
         }
+        STAMP(tC);
+        STAMP_ADD(1, tB, tC);
         for (uint32_t lo = e0; lo < e1;) {
+          STAMP(tD0);
           const uint32_t b = lo & ~1u;
           const uint32_t hi = min(e1, b + TILE);
           double *s_prod = s_buf[TWO ? par : 0u];
@@ -1212,7 +1230,11 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
           } else {
             csr_stage<MODE, EPT>(A, x, ev, b, lo, hi, s_prod, s_col);
           }
+          STAMP(tD);
+          STAMP_ADD(2, tD0, tD);
           __syncthreads();
+          STAMP(tE);
+          STAMP_ADD(3, tD, tE);
 #ifdef ABFT_DBG_NOPHASE2  // timing-only build: wrong results
           if (threadIdx.x == 1023u)
 #endif
@@ -1226,6 +1248,8 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
               acc[j] = t;
             }
           }
+          STAMP(tF);
+          STAMP_ADD(4, tE, tF);
           lo = hi;
         }
       }
@@ -1246,6 +1270,11 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
       atomicAdd(L.debug, dbg_spins);
       atomicAdd(L.debug + 1, dbg_waits);
       atomicAdd(L.debug + 2, 1u);
+#ifdef ABFT_DBG_STAMPS
+      STAMP(t_end);
+      dbg_t[5] = t_end - t_begin;
+      for (int k = 0; k < 6; k++) atomicAdd(reinterpret_cast<unsigned long long *>(L.debug + 4) + k, dbg_t[k]);
+#endif
     }
     // the workgroup that leaves last resets the registrations and the boards for the next launch
     if (threadIdx.x == 0) {
