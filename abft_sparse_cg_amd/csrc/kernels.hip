@@ -382,11 +382,22 @@ __device__ __forceinline__ void csr_stage(const CsrDev &A, const double *__restr
 // Sum one row from the staged products, in ascending element order.  In
 // constraints mode also runs the reference's structural checks in that order
 // (CSR/CPUContext.cpp:186-200).  Returns false if a fatal event was queued.
-template <int MODE>
+template <int MODE, bool SHORT = false>
 __device__ __forceinline__ bool csr_row_sum(const CsrDev &A, const EventRing &ev, uint32_t base,
                                             uint32_t rs, uint32_t re, uint32_t row_end,
                                             const double *s_prod, const uint32_t *s_col,
                                             double &acc, uint32_t row = 0) {
+  if (MODE != MODE_CONSTRAINTS && SHORT) {
+    // the sweep kernel's ranges (a row's elements inside one panel and tile) hold 0-2 elements
+    // nearly always: two reads in flight instead of four halves the LDS instructions of its summing phase
+    for (uint32_t i = rs; i < re; i += 2u) {
+      const uint32_t k = i - base, last = re - 1u - base;
+      const double a0 = s_prod[k], a1 = s_prod[min(k + 1u, last)];
+      acc += a0;
+      if (i + 1u < re) acc += a1;
+    }
+    return true;
+  }
   if (MODE != MODE_CONSTRAINTS) {
     // four LDS reads in flight, then up to four adds in element order; a lane
     // past its row's end re-reads its last slot and skips the add (no "+ 0.0":
@@ -1244,7 +1255,7 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
             const uint32_t a0 = max(start[j], lo), a1 = min(start[j] + cj, hi);
             if (a0 < a1) {
               double t = acc[j];
-              csr_row_sum<MODE>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
+              csr_row_sum<MODE, ABFT_CFG_SWEEP_SHORT_SUMS>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
               acc[j] = t;
             }
           }
