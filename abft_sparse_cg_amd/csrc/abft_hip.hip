@@ -458,7 +458,7 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
   {
     double best = -1.0;
     uint64_t best_rounds = 0;
-    for (int rpt : {2, 4, 8, 16}) {
+    for (int rpt : {2, 4, 8, 16}) {  // (1 row per thread, 8 workgroups per CU: 169 vs 128 us on config 4's 1/8 shard)
       const uint64_t groups = ((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt), cap = std::max<uint64_t>(capacity(rpt), 1);
       const uint64_t rounds = (groups + cap - 1) / cap;
       const double per_cu = std::min(4.0, (double)((groups + rounds - 1) / rounds) / 256.0);

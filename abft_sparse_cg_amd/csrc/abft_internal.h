@@ -122,6 +122,9 @@ struct CooDev {
 #ifndef ABFT_CFG_COO_PANEL_EPT
 #define ABFT_CFG_COO_PANEL_EPT 4  // 16-byte elements per thread per tile of the COO panel kernel
 #endif
+#ifndef ABFT_CFG_COO_PANEL_SHORT_SUMS
+#define ABFT_CFG_COO_PANEL_SHORT_SUMS 1  // COO panel kernel's ordered sums two-wide instead of four-wide
+#endif
 #ifndef ABFT_CFG_SWEEP_SHORT_SUMS
 #define ABFT_CFG_SWEEP_SHORT_SUMS 1  // sweep kernel's row sums: two LDS reads in flight per step instead of four
 #endif

@@ -817,9 +817,24 @@ __device__ __forceinline__ void coo_push_moved(const CooDev &A, const EventRing 
 // Continue the ordered sum of output `out` over LDS slots [a, b) from `acc`: four reads
 // in flight, adds in slot order.  A slot whose staged column is not `out` is left out of
 // the sum (no "+ 0.0") and queued for the fix-up; `j0` = stored position of slot 0.
+template <bool SHORT = false>
 __device__ __forceinline__ void lds_ordered_add(const CooDev &A, const EventRing &ev, const double *s_prod,
                                                 const uint32_t *s_col, uint32_t a, uint32_t b, uint32_t out,
                                                 uint32_t j0, double &acc) {
+  if (SHORT) {  // the panel kernel's ranges (an output's elements inside one panel and tile) are short: two-wide
+    for (uint32_t k = a; k < b; k += 2u) {
+      const uint32_t last = b - 1u, k1 = min(k + 1u, last);
+      const double a0 = s_prod[k], a1 = s_prod[k1];
+      const uint32_t c0 = s_col[k], c1 = s_col[k1];
+      if (c0 == out) acc += a0;
+      if (k + 1u < b && c1 == out) acc += a1;
+      if (__builtin_expect(((c0 ^ out) | (c1 ^ out)) != 0u, 0)) {
+        if (c0 != out) coo_push_moved(A, ev, j0 + k, c0, a0);
+        if (k + 1u < b && c1 != out) coo_push_moved(A, ev, j0 + k + 1u, c1, a1);
+      }
+    }
+    return;
+  }
   for (uint32_t k = a; k < b; k += 4u) {
     const uint32_t last = b - 1u;
     const uint32_t k1 = min(k + 1u, last), k2 = min(k + 2u, last), k3 = min(k + 3u, last);
@@ -940,8 +955,8 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
           const uint32_t a0 = max(gs[j], lo), a1 = min(ge[j], hi);
           if (a0 < a1) {
             double t = acc[j];
-            lds_ordered_add(A, ev, s_prod, s_col, a0 - lo, a1 - lo, out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x,
-                            lo, t);
+            lds_ordered_add<ABFT_CFG_COO_PANEL_SHORT_SUMS>(A, ev, s_prod, s_col, a0 - lo, a1 - lo,
+                                                           out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x, lo, t);
             acc[j] = t;
           }
         }
