@@ -135,6 +135,11 @@ void Comm::connect_star(const char *addr, int port)
       send_all(fd, &kMagic, sizeof(kMagic));
       peers_[who] = fd;
     }
+    // everyone is here: stop listening, so that a rank of a job started right behind this one
+    // (bench.py runs two in a row on the same port) is refused and retries until ITS rank 0 is up,
+    // instead of queueing on a socket nobody will accept from again
+    close(listen_fd_);
+    listen_fd_ = -1;
     return;
   }
   sockaddr_in sa;

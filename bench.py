@@ -282,6 +282,9 @@ def cpp_job(args, spec, mode, fmt, profile):
     return out
 
 
+EXTRA_SPEC_MULTI = os.environ.get("ABFT_BENCH_EXTRA_SPEC", "random:4194304,24,1")  # (override: tests)
+
+
 def multi(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -291,7 +294,7 @@ def multi(args):
     extra = None
     if args.extras:
         # the configuration the multi-GPU target is quoted on (BASELINE.json configs[3]): same path
-        extra = cpp_job(args, "random:4194304,24,1", "secded", "csr", not args.no_profile)
+        extra = cpp_job(args, EXTRA_SPEC_MULTI, "secded", "csr", not args.no_profile)
     if rank != 0:
         return None
 
@@ -351,7 +354,7 @@ def main():
                                "rr_after_last_step": hl["rr_after_last_step"]},
                     "roofline": roof, "cpu_baseline": None})
         if xl:
-            xl["workload"] = "cg-csr -t hip -m secded, synthetic random:4194304,24,1 (BASELINE.json configs[3])"
+            xl["workload"] = "cg-csr -t hip -m secded, synthetic %s (BASELINE.json configs[3])" % EXTRA_SPEC_MULTI
             out["extra_legs"] = {"config4": xl}
         print(json.dumps(out))
 

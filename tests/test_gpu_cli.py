@@ -370,3 +370,20 @@ def test_bench_py_multi_rank_path_runs_the_cpp_driver():
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0 and d["config"]["N"] == 90000
     assert d["roofline"]["avg_launch_us"] > 0 and "C++ host over RCCL" in d["config"]["parallelism"]
+
+
+def test_bench_py_under_the_launcher_two_ranks_two_jobs():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per process; here both
+    ranks on the one GPU with host-staged collectives): every rank starts cg-csr --bench, twice in a row
+    on the same rendezvous port (headline + the extra leg), rank 0 prints one JSON line."""
+    env = dict(os.environ, ABFT_COMM="tcp", ABFT_HIP_DEVICE="0", ABFT_BENCH_EXTRA_SPEC="random:16384,12,3")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(23000 + os.getpid() % 6000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "8", "--warmup", "3", "--spec", "laplace5:200,200", "--mode", "secded"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-800:] + p.stderr[-2500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["N"] == 40000 and d["scaling"] == "strong"
+    assert d["extra_legs"]["config4"]["N"] == 16384 and d["extra_legs"]["config4"]["it_per_s"] > 0
