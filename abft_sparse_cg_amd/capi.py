@@ -49,6 +49,7 @@ SIGNATURES = {
     "abft_hip_set_stream": (C.c_int, [vp, vp]),
     "abft_hip_get_stream": (vp, [vp]),
     "abft_hip_synchronize": (C.c_int, [vp]),
+    "abft_hip_synchronize_timeout": (C.c_int, [vp, C.c_double]),
     "abft_hip_matrix_create_csr": (C.c_int, [vp, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int, vpp]),
     "abft_hip_matrix_create_coo": (C.c_int, [vp, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int, vpp]),
     "abft_hip_matrix_create_shard": (C.c_int, [vp, C.c_int, C.c_int, u32p, u32p, f64p, C.c_int, C.c_int,

@@ -4,11 +4,13 @@
 // kernels.hip.  Nothing here prints or exits; nothing here falls back to a CPU
 // path -- a failing HIP call surfaces as ABFT_ERR_HIP.
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "abft_internal.h"
@@ -286,6 +288,21 @@ extern "C" int abft_hip_synchronize(abft_hip_ctx *ctx) {
   if (int rc = bind(ctx)) return rc;
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return ABFT_OK;
+}
+
+// wait for the stream, but not for ever: ABFT_ERR_HIP with "timed out" if `seconds` pass first
+// (a first replay of a freshly captured graph that holds collectives is waited for this way)
+extern "C" int abft_hip_synchronize_timeout(abft_hip_ctx *ctx, double seconds) {
+  if (int rc = bind(ctx)) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) return ABFT_OK;
+    if (q != hipErrorNotReady) return set_err(ABFT_ERR_HIP, "stream failed: %s", hipGetErrorString(q));
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > seconds)
+      return set_err(ABFT_ERR_HIP, "timed out after %.0f s waiting for the stream", seconds);
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
 }
 
 // ------------------------------------------------------------------- matrix --

@@ -7,6 +7,7 @@
 #include <cstring>
 
 #include <chrono>
+#include <unistd.h>
 
 #include "comm.h"
 #include "partition.h"
@@ -17,6 +18,7 @@ HIPContextBase::HIPContextBase(int format, int mode)
     fixed_scal_(NULL), fixed_scal_dev_(NULL)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
+  replayed_[0] = replayed_[1] = false;
   int device = comm_ ? comm_->local_rank() : 0;
   if (const char *env = getenv("ABFT_HIP_DEVICE"))
     device = atoi(env);
@@ -647,7 +649,22 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
           continue;
         }
       }
+      const bool first_replay = !replayed_[parity];
       check(abft_hip_graph_launch(fixed_graph_[parity]), "abft_hip_graph_launch");
+      if (first_replay && comm_)
+      {
+        // a fresh capture that holds collectives: wait for its first replay under a deadline, so
+        // that a stack on which they cannot run from a graph ends the job with a message
+        // (ABFT_CG_GRAPH=0 avoids graphs) instead of hanging it
+        replayed_[parity] = true;
+        if (abft_hip_synchronize_timeout(ctx_, 180.0) != ABFT_OK)
+        {
+          fflush(stdout);
+          fprintf(stderr, "hip backend: the first hipGraph replay of the CG iteration did not finish (%s); "
+                  "rerun with ABFT_CG_GRAPH=0\n", abft_hip_last_error());
+          _exit(70);
+        }
+      }
     }
     else
       fixed_iteration(A, x, r, p, w, parity);

@@ -118,6 +118,7 @@ private:
   abft_hip_vector *fixed_scal_;
   double *fixed_scal_dev_;
   abft_hip_graph *fixed_graph_[2];
+  bool replayed_[2];             // the graph of that parity has completed a replay
 };
 
 template<int FORMAT, int MODE>

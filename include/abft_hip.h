@@ -96,6 +96,10 @@ int abft_hip_shutdown(abft_hip_ctx *ctx);
 int abft_hip_set_stream(abft_hip_ctx *ctx, void *hip_stream);
 void *abft_hip_get_stream(abft_hip_ctx *ctx);
 int abft_hip_synchronize(abft_hip_ctx *ctx);
+/* The same, giving up after `seconds` (ABFT_ERR_HIP, "timed out"): for the first replay of a
+ * captured graph that holds collectives, so that a stack on which they cannot run from a graph
+ * ends the job with a message instead of hanging it. */
+int abft_hip_synchronize_timeout(abft_hip_ctx *ctx, double seconds);
 
 /* ---- matrix ------------------------------------------------------------ */
 
