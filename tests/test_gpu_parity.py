@@ -213,6 +213,32 @@ def test_constraints_mode_detects_like_reference(amd, fmt):
     assert fatal_seen > 20
 
 
+def test_event_queue_overflow_is_reported_not_hidden(amd):
+    """More events than the device queue holds (65 536): the drain hands over what was kept and
+    fails loudly (ABFT_ERR_RANGE) -- a run past this point would no longer print the reference's
+    lines, and dropping the surplus silently could hide a fatal one."""
+    from abft_sparse_cg_amd import capi
+    cols, rows, vals, n = laplace5(130, 130)
+    assert len(vals) > 70000
+    ctx = amd.HIPContext("sec7", "csr", on_event=lambda ev, fatal: None)
+    try:
+        A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+        for i in range(66000):
+            ctx.inject_at(A, i, [3])
+        vx, vy = ctx.create_vector(n), ctx.create_vector(n)
+        ctx.upload(vx, rhs(n, 1))
+        capi.check(ctx.L.abft_hip_spmv(ctx.h, A.h, vx.h, vy.h))
+        with pytest.raises(amd.AbftError) as e:
+            ctx.drain_events()
+        assert e.value.code == -4 and "overflow" in str(e.value) and "66000" in str(e.value)
+        # the queue is empty again and the repaired matrix multiplies cleanly
+        capi.check(ctx.L.abft_hip_spmv(ctx.h, A.h, vx.h, vy.h))
+        assert ctx.drain_events() == ([], False)
+        assert bits_equal(ctx.download(vy), OracleMatrix(CSR, "sec7", cols, rows, vals, n).spmv(rhs(n, 1)))
+    finally:
+        ctx.close()
+
+
 def test_constraints_mode_row_pointer_checks(amd):
     """The two checks no element flip reaches (reference CSR/CPUContext.cpp:173-182: "row size" when
     a row's end lies past nnz, "row order" when it lies before its start): a bit of a row pointer
