@@ -7,12 +7,14 @@
 #include <poll.h>
 #include <sys/socket.h>
 #include <sys/time.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 static void die(const char *what)
 {
@@ -29,8 +31,57 @@ static int env_int(const char *name, int fallback)
   return v && *v ? atoi(v) : fallback;
 }
 
+// ABFT_HIP_GPUS=N without a launcher: the process starts the other N - 1 ranks itself, before
+// anything has touched a GPU (plain fork: every rank then runs the unchanged driver from where
+// the backend was created; SURVEY 5 names the variable).  Returns the children's pids.
+static std::vector<int> g_children;
+
+static void self_launch(int n)
+{
+  // a free port for the rendezvous: ask the kernel for one, then let it go again
+  int port = 29400;
+  int probe = socket(AF_INET, SOCK_STREAM, 0);
+  if (probe >= 0)
+  {
+    sockaddr_in sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sin_family = AF_INET;
+    sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+    socklen_t len = sizeof(sa);
+    if (bind(probe, (sockaddr *)&sa, sizeof(sa)) == 0 && getsockname(probe, (sockaddr *)&sa, &len) == 0)
+      port = ntohs(sa.sin_port);
+    close(probe);
+  }
+  char buf[32];
+  setenv("MASTER_ADDR", "127.0.0.1", 1);
+  snprintf(buf, sizeof(buf), "%d", port);
+  setenv("MASTER_PORT", buf, 1);
+  snprintf(buf, sizeof(buf), "%d", n);
+  setenv("WORLD_SIZE", buf, 1);
+  setenv("RANK", "0", 1);
+  setenv("LOCAL_RANK", "0", 1);
+  fflush(stdout);
+  fflush(stderr);
+  for (int r = 1; r < n; r++)
+  {
+    const pid_t pid = fork();
+    if (pid < 0) die("fork");
+    if (pid == 0)
+    {
+      snprintf(buf, sizeof(buf), "%d", r);
+      setenv("RANK", buf, 1);
+      setenv("LOCAL_RANK", buf, 1);
+      g_children.clear();
+      return;
+    }
+    g_children.push_back((int)pid);
+  }
+}
+
 Comm* Comm::from_env()
 {
+  if (env_int("WORLD_SIZE", 0) == 0 && env_int("ABFT_HIP_GPUS", 1) > 1)
+    self_launch(env_int("ABFT_HIP_GPUS", 1));
   const int world = env_int("WORLD_SIZE", 1);
   // (ABFT_COMM_FORCE=1: take the partitioned code path -- and RCCL -- with a single rank, for tests)
   if (world <= 1 && env_int("ABFT_COMM_FORCE", 0) == 0)
@@ -65,6 +116,12 @@ Comm::~Comm()
       close(peers_[i]);
   if (listen_fd_ >= 0)
     close(listen_fd_);
+  for (size_t i = 0; i < g_children.size(); i++)  // ABFT_HIP_GPUS: the ranks this process started
+  {
+    int status = 0;
+    waitpid((pid_t)g_children[i], &status, 0);
+  }
+  g_children.clear();
 }
 
 void Comm::enable_device_collectives(int device)

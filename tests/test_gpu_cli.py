@@ -387,3 +387,21 @@ def test_bench_py_under_the_launcher_two_ranks_two_jobs():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["N"] == 40000 and d["scaling"] == "strong"
     assert d["extra_legs"]["config4"]["N"] == 16384 and d["extra_legs"]["config4"]["it_per_s"] > 0
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_abft_hip_gpus_starts_the_ranks_itself(fmt):
+    """ABFT_HIP_GPUS=N and no launcher: the executable forks the other ranks before touching a GPU
+    (here all on GPU 0, host-staged collectives) -- same transcript as one process."""
+    args = ["-f", MTX, "-t", "hip", "-m", "secded", "--flip-at", "1234:70"]
+    one = run(fmt, args)
+    env = dict(os.environ, ABFT_HIP_GPUS="3", ABFT_COMM="tcp", ABFT_HIP_DEVICE="0", ABFT_HIP_VERBOSE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    many = subprocess.run([exe(fmt)] + args, capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0 and many.returncode == 0, many.stdout[-400:] + many.stderr[-1200:]
+    (rr1, rest1), (rrn, restn) = split_transcript(one.stdout), split_transcript(many.stdout)
+    assert len(rr1) == len(rrn) > 50 and all(abs(a - b) <= 1.01e-4 + 1e-10 * a for a, b in zip(rr1, rrn))
+    norm = lambda t: re.sub(r"(total error|max error) += +[0-9.]+", lambda m: m.group(0)[:-2], t).lstrip("\n")  # noqa: E731
+    assert norm(rest1) == norm(restn)
+    assert len([l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]) == 3
