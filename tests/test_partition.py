@@ -107,3 +107,27 @@ def test_partitioned_cg_over_gloo_matches_one_process(fmt, world, matrix):
     if matrix == "laplace":
         lo, hi = out["interior"]
         assert hi - lo > (out["bounds"][1] - out["bounds"][0]) // 2
+
+
+def test_planner_awkward_shapes():
+    """few rows per rank, all non-zeros in one row, empty rows at the cuts, as many ranks as rows"""
+    from _partition_worker import plan
+    L = lib()
+    n = 7
+    rows = np.array([3] * 7 + [6], np.uint32)          # everything in row 3, one element in the last row
+    cols = np.array([0, 1, 2, 3, 4, 5, 6, 6], np.uint32)
+    vals = np.arange(1.0, 9.0)
+    for fmt in (0, 1):
+        for world in (1, 2, 4, 7):
+            plans = [plan(L, fmt, cols, rows, vals, n, world, me) for me in range(world)]
+            b = plans[0]["bounds"]
+            assert b[0] == 0 and b[-1] == n and all(b[g + 1] > b[g] for g in range(world))  # one output each at least
+            seen = np.zeros(len(vals), int)
+            for p in plans:
+                seen[p["gidx"]] += 1
+            assert np.all(seen == 1)
+    import ctypes as C
+    u32p = C.POINTER(C.c_uint32)
+    rc = L.abft_plan_shard(0, cols.ctypes.data_as(u32p), rows.ctypes.data_as(u32p), vals.ctypes.data_as(C.POINTER(C.c_double)),
+                           C.c_longlong(8), 7, 8, 0, None, None, None, None, None, None, C.c_longlong(0))
+    assert rc == 1  # more ranks than rows: refused (the backend exits with a message)
