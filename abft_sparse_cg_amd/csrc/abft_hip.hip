@@ -5,6 +5,7 @@
 // path -- a failing HIP call surfaces as ABFT_ERR_HIP.
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -491,11 +492,23 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
   // entries of the gathered vector per panel: 1 MB of it (2 MB: 757 vs 743 us on config 4) unless that
   // leaves a segment well under two tiles on average -- the 1/8 row shard of config 4 that one rank
   // of an 8-GPU job multiplies: 161 us with 1 MB panels, 134 us with 2 MB ones
+  // Inside that range the width is set so that the average segment just fills a whole number of
+  // tiles: every tile costs its full load phase, so a segment of 1.6 tiles pays for 2 (config 4,
+  // 16 rows per thread: 3 277 elements per segment at 2^17 entries, 724 us; 4 000 at 164 000 entries
+  // -- two tiles less 1.5 standard deviations -- 681 us; 4 300, where most segments spill into a third
+  // tile, 737 us; `gpurun_out/r2/width_ab2.log`)
   uint32_t width = 1u << 17;
   {
     const uint64_t groups = ((uint64_t)n_out + 256u * sb.rpt - 1) / (256u * sb.rpt);
-    const uint64_t tile = 256u * (sb.rpt <= 4 ? 4u : 8u);
-    if ((uint64_t)nnz * 2 < 3 * tile * groups * (((uint64_t)n_in + width - 1) / width)) width = 1u << 18;
+    const double tile = 256.0 * (sb.rpt <= 4 ? 4.0 : 8.0);
+    const double per_entry = (double)nnz / ((double)groups * (double)n_in);  // elements of a segment per entry of x
+    if ((double)width * per_entry * 2.0 < 3.0 * tile) width = 1u << 18;
+    for (int k = 1; k <= 8; k++) {
+      const double w = (k * tile - 1.5 * std::sqrt(k * tile)) / per_entry;
+      if (w < 0.92 * (double)(1u << 17)) continue;
+      if (w <= 1.25 * (double)(1u << 18)) width = (uint32_t)w & ~15u;
+      break;
+    }
   }
   if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
   const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
@@ -572,8 +585,7 @@ static int finish_sweep(abft_hip_matrix *m, const SweepBuild &sb, uint32_t capac
   // all groups resident if they fit; else equal rounds
   const uint32_t rounds = (sb.ngroups + capacity - 1) / capacity;
   m->sweep_grid = (sb.ngroups + rounds - 1) / rounds;
-  std::vector<uint32_t> init(16 + 8 * 256, 0xffffffffu);  // PACE_HDR zeros + 8 boards of PACE_SLOTS "nobody here"
-  std::fill(init.begin(), init.begin() + 16, 0u);
+  std::vector<uint32_t> init(8 * 256, 0xffffffffu);  // 8 boards of PACE_SLOTS "nobody here"
   if ((rc = dev_upload(m, &d_pace, init.data(), init.size(), init.size()))) return rc;
   HIPCHK(hipStreamSynchronize(m->ctx->stream));  // `init` goes out of scope
   m->use_sweep = true;

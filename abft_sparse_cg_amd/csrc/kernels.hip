@@ -1038,9 +1038,9 @@ hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y
 
 // ------------------------------------------------------------ sweep-layout SpMV --
 
-// pace buffer: [0] exit ticket, [1..9) workgroups registered per XCD, then per XCD a board of
-// PACE_SLOTS progress words (steps completed by the workgroup that drew that slot; ~0u = none)
-constexpr uint32_t PACE_HDR = 16, PACE_SLOTS = 256;
+// pace buffer: per XCD a board of PACE_SLOTS progress words (steps completed by the workgroup
+// that owns that slot; ~0u = nobody there, which is also how every workgroup leaves its slot)
+constexpr uint32_t PACE_SLOTS = 256;
 
 // which of the 8 XCDs (each with its own L2) this wave runs on
 __device__ __forceinline__ uint32_t xcc_id() {
@@ -1134,7 +1134,6 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
   constexpr bool TWO = RPT == 16 || EPT <= 4;
   __shared__ __attribute__((aligned(16))) double s_buf[TWO ? 2 : 1][TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
-  __shared__ uint32_t s_last;
   uint32_t par = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1144,12 +1143,13 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
   uint32_t *board = nullptr;       // this XCD's progress board
   uint32_t my_slot = 0xffffffffu;  // wave 0: where this workgroup publishes (only lane 0 stores)
   if (pace) {
-    const uint32_t xcd = xcc_id();
-    board = L.pace + PACE_HDR + xcd * PACE_SLOTS;
+    // slot = blockIdx / 8: workgroups are dealt to the XCDs round-robin, so the slots of one board
+    // are distinct (were two workgroups of an XCD ever to share one, the board would show the later
+    // writer: pacing a little less exact, nothing else).  No registration, no exit ticket: the two
+    // agent-scope atomics per workgroup those took cost more than the pacing gained.
+    board = L.pace + xcc_id() * PACE_SLOTS;
     if (wave == 0u) {
-      uint32_t t = 0;
-      if (lane == 0u) t = __hip_atomic_fetch_add(L.pace + 1u + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      my_slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      my_slot = blockIdx.x >> 3;
       if (lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = 0u;
     }
   }
@@ -1302,18 +1302,8 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
       for (int k = 0; k < 6; k++) atomicAdd(reinterpret_cast<unsigned long long *>(L.debug + 4) + k, dbg_t[k]);
 #endif
     }
-    // the workgroup that leaves last resets the registrations and the boards for the next launch
-    if (threadIdx.x == 0) {
-      if (my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;  // done: never holds anyone back
-      s_last = __hip_atomic_fetch_add(L.pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
-    }
-    __syncthreads();
-    if (s_last) {
-      for (uint32_t i = threadIdx.x; i < PACE_HDR; i += ABFT_BLOCK)
-        __hip_atomic_store(L.pace + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (uint32_t i = threadIdx.x; i < 8u * PACE_SLOTS; i += ABFT_BLOCK)
-        __hip_atomic_store(L.pace + PACE_HDR + i, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    // done: never holds anyone back, and the board is clean for the next launch
+    if (threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;
   }
 }
 
