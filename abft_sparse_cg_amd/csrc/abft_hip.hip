@@ -500,7 +500,7 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
   uint32_t width = 1u << 17;
   {
     const uint64_t groups = ((uint64_t)n_out + 256u * sb.rpt - 1) / (256u * sb.rpt);
-    const double tile = 256.0 * (sb.rpt <= 4 ? 4.0 : 8.0);
+    const double tile = 256.0 * (sb.rpt <= 4 ? 4.0 : (double)ABFT_CFG_SWEEP_EPT);
     const double per_entry = (double)nnz / ((double)groups * (double)n_in);  // elements of a segment per entry of x
     if ((double)width * per_entry * 2.0 < 3.0 * tile) width = 1u << 18;
     for (int k = 1; k <= 8; k++) {
