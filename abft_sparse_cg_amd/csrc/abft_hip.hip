@@ -489,7 +489,7 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
     const int v = atoi(r);
     if (v == 2 || v == 4 || v == 8 || v == 16) sb.rpt = v;
   }
-  // entries of the gathered vector per panel: 1 MB of it (2 MB: 757 vs 743 us on config 4) unless that
+  // entries of the gathered vector per panel: about 1 MB of it (2 MB: 757 vs 743 us on config 4) unless that
   // leaves a segment well under two tiles on average -- the 1/8 row shard of config 4 that one rank
   // of an 8-GPU job multiplies: 161 us with 1 MB panels, 134 us with 2 MB ones
   // Inside that range the width is set so that the average segment just fills a whole number of
