@@ -83,6 +83,14 @@ struct abft_hip_ctx {
   unsigned prof_stride = 1, prof_seen[ABFT_K_COUNT] = {};  // ... every prof_stride-th launch of it
   ProfSlot prof_k[ABFT_K_COUNT];
   std::vector<hipEvent_t> ev_pool;
+  // peer board (abft_hip_peer_board_attach): the caller's mapping, its device alias, this rank
+  struct {
+    void *host = nullptr;
+    PeerSlot *dev = nullptr;
+    unsigned long long *counter = nullptr;  // device: sequence number of the last all-reduce
+    int rank = 0, size = 0;
+    unsigned long long timeout_ticks = 0;
+  } peers;
 };
 
 struct abft_hip_matrix {
@@ -271,6 +279,7 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipFree(ctx->moved.buf);
   (void)hipFree(ctx->moved.count);
   (void)hipFree(ctx->bits_dev);
+  (void)abft_hip_peer_board_detach(ctx);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ABFT_OK;
@@ -1256,6 +1265,73 @@ extern "C" int abft_hip_write_pair(abft_hip_ctx *ctx, double *dev_pair, double v
   HIPCHK(hipMemcpyAsync(dev_pair, v, sizeof(v), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));  // `v` is on the stack
   return ABFT_OK;
+}
+
+// ---- all-reduce of a pair across the processes of one node, over a shared board ----
+
+extern "C" size_t abft_hip_peer_board_bytes(void) { return (ABFT_PEER_BOARD_BYTES + 4095) & ~(size_t)4095; }
+
+extern "C" int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, int rank, int size,
+                                          double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!shared || bytes < abft_hip_peer_board_bytes() || ((uintptr_t)shared & 4095u))
+    return set_err(ABFT_ERR_INVALID, "peer board: a page-aligned mapping of at least %zu bytes is needed",
+                   abft_hip_peer_board_bytes());
+  if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
+    return set_err(ABFT_ERR_RANGE, "peer board: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
+  if (ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: already attached");
+  if (hipHostRegister(shared, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(ABFT_ERR_HIP, "peer board: hipHostRegister of the shared mapping failed");
+  }
+  void *dev = nullptr;
+  unsigned long long *counter = nullptr;
+  if (hipHostGetDevicePointer(&dev, shared, 0) != hipSuccess || hipMalloc((void **)&counter, sizeof(*counter)) != hipSuccess ||
+      hipMemsetAsync(counter, 0, sizeof(*counter), ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(shared);
+    (void)hipFree(counter);
+    return set_err(ABFT_ERR_HIP, "peer board: no device view of the shared mapping");
+  }
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+  ctx->peers.host = shared;
+  ctx->peers.dev = (PeerSlot *)dev;
+  ctx->peers.counter = counter;
+  ctx->peers.rank = rank;
+  ctx->peers.size = size;
+  ctx->peers.timeout_ticks = (unsigned long long)((timeout_seconds > 0 ? timeout_seconds : 120.0) * 1e3 * khz);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_board_detach(abft_hip_ctx *ctx) {
+  if (!ctx || !ctx->peers.host) return ABFT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipHostUnregister(ctx->peers.host);
+  (void)hipFree(ctx->peers.counter);
+  (void)hipGetLastError();  // (a failed unregister must not surface at the next launch check)
+  ctx->peers = {};
+  return ABFT_OK;
+}
+
+// dev_pair[0..2) += over the ranks of the board, in place, enqueued on the context's stream
+extern "C" int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!dev_pair) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (!ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
+  uint32_t *fail = reinterpret_cast<uint32_t *>(ctx->peers.dev + 2 * ABFT_PEER_MAX_RANKS);
+  HIPCHK(launch_peer_allreduce(dev_pair, ctx->peers.dev, ctx->peers.counter, fail, ctx->peers.rank, ctx->peers.size,
+                               ctx->peers.timeout_ticks, ctx->stream));
+  return ABFT_OK;
+}
+
+// 1 if an all-reduce of this rank gave up waiting for a peer (its result was NaN)
+extern "C" int abft_hip_peer_board_failed(abft_hip_ctx *ctx) {
+  if (!ctx || !ctx->peers.host) return 0;
+  const volatile uint32_t *fail =
+      reinterpret_cast<const volatile uint32_t *>(static_cast<PeerSlot *>(ctx->peers.host) + 2 * ABFT_PEER_MAX_RANKS);
+  return fail[ctx->peers.rank] != 0;
 }
 
 // ---- device-scalar forms: alpha and beta never leave the GPU -------------------

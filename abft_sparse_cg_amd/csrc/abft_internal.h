@@ -267,6 +267,16 @@ hipError_t launch_calc_px(double *p, const double *r, double *x, double beta, co
                           double alpha, const double *alpha_ptr, int n, hipStream_t s);
 hipError_t launch_axpy(double *x, const double *p, double alpha, const double *alpha_ptr, int n, hipStream_t s);
 hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq, hipStream_t s);
+
+// peer board (all-reduce of a pair across the processes of one node, see kernels.hip):
+// [2 rows][ABFT_PEER_MAX_RANKS] slots, then one failure flag per rank
+#define ABFT_PEER_MAX_RANKS 64
+struct PeerSlot {
+  unsigned long long v0, v1, seq, pad;
+};
+#define ABFT_PEER_BOARD_BYTES (2 * ABFT_PEER_MAX_RANKS * sizeof(PeerSlot) + ABFT_PEER_MAX_RANKS * sizeof(uint32_t))
+hipError_t launch_peer_allreduce(double *pair, PeerSlot *board, unsigned long long *counter, uint32_t *fail, int rank,
+                                 int size, unsigned long long timeout_ticks, hipStream_t s);
 hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s);
 hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s);
 hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s);

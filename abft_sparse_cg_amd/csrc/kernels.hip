@@ -1848,6 +1848,82 @@ hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq,
   return hipGetLastError();
 }
 
+// ---------------------------------------------- all-reduce of a pair over a peer board --
+//
+// The two scalar reductions of a CG iteration across the processes of one node (one per
+// GPU), without a collective library: 16 bytes per rank.  The board is a few KB of pinned
+// host memory that every process of the job has mapped and registered (POSIX shared memory),
+// two rows (the parity of the reduction's sequence number) of one 32-byte slot per rank.  A
+// rank stores {value, events} and then the sequence number into ITS slot with system-scope
+// stores -- posted writes of one device arrive in order -- and the lanes of one wave poll the
+// slots of all ranks until they carry this sequence number; lane 0 adds them in rank order,
+// so every rank forms the same bits.  Two rows are enough: a rank can start reduction k + 1
+// (other row) before a slow peer has read row k, but not k + 2, which needs that peer's
+// k + 1.  One kernel node: capturable, nothing to set up at first use, and the latency is two
+// PCIe crossings instead of a collective's launch and protocol.  Every wait is bounded; a
+// rank that gives up leaves NaN and raises its flag on the board.
+__global__ __launch_bounds__(64) void peer_allreduce_kernel(double *pair, PeerSlot *board,
+                                                            unsigned long long *counter, uint32_t *fail, int rank,
+                                                            int size, unsigned long long timeout_ticks) {
+  __shared__ double s_v[2][ABFT_PEER_MAX_RANKS];
+  __shared__ uint32_t s_bad;
+  const int lane = (int)threadIdx.x;
+  const unsigned long long seq = *counter + 1ull;  // written by the previous launch on this stream
+  PeerSlot *row = board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS;
+  if (lane == 0) {
+    s_bad = 0u;
+    __hip_atomic_store(&row[rank].v0, (unsigned long long)__double_as_longlong(pair[0]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&row[rank].v1, (unsigned long long)__double_as_longlong(pair[1]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&row[rank].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  double a = 0.0, b = 0.0;
+  if (lane < size) {
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(&row[lane].seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (ok) {
+      a = __longlong_as_double((long long)__hip_atomic_load(&row[lane].v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      b = __longlong_as_double((long long)__hip_atomic_load(&row[lane].v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    } else {
+      atomicOr(&s_bad, 1u);
+    }
+    s_v[0][lane] = a;
+    s_v[1][lane] = b;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < size; r++) {
+      s0 += s_v[0][r];
+      s1 += s_v[1][r];
+    }
+    if (s_bad) {
+      s0 = __longlong_as_double(0x7ff8000000000000ll);
+      __hip_atomic_store(fail + rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    pair[0] = s0;
+    pair[1] = s1;
+    *counter = seq;
+  }
+}
+
+hipError_t launch_peer_allreduce(double *pair, PeerSlot *board, unsigned long long *counter, uint32_t *fail, int rank,
+                                 int size, unsigned long long timeout_ticks, hipStream_t s) {
+  hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(64), 0, s, pair, board, counter, fail, rank, size,
+                     timeout_ticks);
+  return hipGetLastError();
+}
+
 // copy_vector (reference CSR/CPUContext.cpp:76-80: memcpy of dst->N doubles), as an
 // ordinary kernel on the context's stream (capturable; no runtime copy path involved)
 template <int VEC>

@@ -7,6 +7,9 @@
 #include <cstring>
 
 #include <chrono>
+#include <cmath>
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include "comm.h"
@@ -15,7 +18,7 @@
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
     r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
-    fixed_scal_(NULL), fixed_scal_dev_(NULL)
+    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
   replayed_[0] = replayed_[1] = false;
@@ -31,7 +34,112 @@ HIPContextBase::HIPContextBase(int format, int mode)
     // every process runs the whole driver; the job's stdout is rank 0's
     if (comm_->rank() != 0 && !freopen("/dev/null", "w", stdout))
       exit(2);
+    setup_peer_board();
   }
+}
+
+// The two scalar all-reduces of an iteration go over a board in shared host memory when all
+// ranks sit on one node (they do: one process per GPU of a node): one small kernel each, no
+// collective library in the iteration's critical path.  ABFT_COMM_ALLREDUCE=rccl (or tcp) keeps
+// them on the collective layer; default: the board if every rank could attach it and a few
+// test sums came out right, else the collective layer -- decided together, so all ranks agree.
+void HIPContextBase::setup_peer_board()
+{
+  const char *env = getenv("ABFT_COMM_ALLREDUCE");
+  if (env && strcmp(env, "board") && strcmp(env, "auto"))
+    return;
+  const int size = comm_->size(), rank = comm_->rank();
+  char host[64];
+  memset(host, 0, sizeof(host));
+  gethostname(host, sizeof(host) - 1);
+  std::vector<char> hosts((size_t)size * sizeof(host));
+  comm_->allgather(host, sizeof(host), hosts.data());
+  bool one_node = true;
+  for (int r = 0; r < size; r++)
+    one_node = one_node && !memcmp(&hosts[(size_t)r * sizeof(host)], host, sizeof(host));
+  board_bytes_ = abft_hip_peer_board_bytes();
+  char name[96];
+  memset(name, 0, sizeof(name));
+  int fd = -1;
+  if (rank == 0 && one_node && size <= 64)
+  {
+    snprintf(name, sizeof(name), "/abft_cg_board_%ld_%lld", (long)getpid(),
+             (long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)board_bytes_) != 0)  // (a fresh object reads as zeros)
+    {
+      if (fd >= 0) { close(fd); shm_unlink(name); fd = -1; }
+      name[0] = 0;
+    }
+  }
+  comm_->bcast(name, sizeof(name), 0);
+  bool ok = name[0] != 0;
+  if (ok && rank != 0)
+    fd = shm_open(name, O_RDWR, 0);
+  void *map = MAP_FAILED;
+  if (ok && fd >= 0)
+    map = mmap(NULL, board_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (fd >= 0)
+    close(fd);
+  ok = ok && map != MAP_FAILED;
+  double timeout = 120.0;
+  if (const char *t = getenv("ABFT_COMM_TIMEOUT"))
+    timeout = atof(t) > 0 ? atof(t) : timeout;
+  bool attached = ok && abft_hip_peer_board_attach(ctx_, map, board_bytes_, rank, size, timeout) == ABFT_OK;
+  double agree = attached ? 1.0 : 0.0;
+  comm_->allreduce_sum(&agree, 1);  // also: everybody has mapped the object by now
+  if (rank == 0 && name[0])
+    shm_unlink(name);
+  bool all = agree == (double)size;
+  for (int t = 0; t < 3 && all; t++)
+  {
+    // {rank + 1 + t, 1} summed over ranks
+    check(abft_hip_write_pair(ctx_, pair_dev_, (double)(rank + 1 + t), 1.0), "abft_hip_write_pair");
+    check(abft_hip_allreduce_pair_peers(ctx_, pair_dev_), "abft_hip_allreduce_pair_peers");
+    double v = 0.0, e = 0.0;
+    check(abft_hip_read_pair(ctx_, pair_dev_, &v, &e), "abft_hip_read_pair");
+    const bool right = v == 0.5 * size * (size + 1) + (double)t * size && e == (double)size;
+    agree = right ? 1.0 : 0.0;
+    comm_->allreduce_sum(&agree, 1);
+    all = agree == (double)size;
+  }
+  if (!all)
+  {
+    if (attached)
+      abft_hip_peer_board_detach(ctx_);
+    if (map != MAP_FAILED)
+      munmap(map, board_bytes_);
+    if (env && !strcmp(env, "board"))
+    {
+      fprintf(stderr, "hip backend: ABFT_COMM_ALLREDUCE=board, but the board could not be set up on every rank\n");
+      exit(2);
+    }
+    return;
+  }
+  board_map_ = map;
+  peers_ok_ = true;
+  if (getenv("ABFT_HIP_VERBOSE") && rank == 0)
+    fprintf(stderr, "hip backend: scalar all-reduces over the peer board (%d ranks, %s)\n", size, host);
+}
+
+void HIPContextBase::check_peer_board()
+{
+  if (peers_ok_ && abft_hip_peer_board_failed(ctx_))
+  {
+    fflush(stdout);
+    fprintf(stderr, "hip backend: rank %d gave up waiting for a peer in an all-reduce (peer board)\n", comm_->rank());
+    exit(2);
+  }
+}
+
+void HIPContextBase::device_allreduce(double *dev_pair)
+{
+  if (peers_ok_)
+    check(abft_hip_allreduce_pair_peers(ctx_, dev_pair), "abft_hip_allreduce_pair_peers");
+  else if (comm_->device_collectives())
+    comm_->allreduce_sum_device(dev_pair, 2, abft_hip_get_stream(ctx_));
+  else
+    staged_allreduce(dev_pair);
 }
 
 HIPContextBase::~HIPContextBase()
@@ -46,7 +154,9 @@ HIPContextBase::~HIPContextBase()
       abft_hip_vector_destroy(fixed_scal_);
     if (pair_)
       abft_hip_vector_destroy(pair_);
-    abft_hip_shutdown(ctx_);
+    abft_hip_shutdown(ctx_);  // (detaches the peer board)
+    if (board_map_)
+      munmap(board_map_, board_bytes_);
   }
   if (comm_)
   {
@@ -129,11 +239,15 @@ double HIPContextBase::reduce_scalar(abft_hip_vector *pair)
   double v[2] = {0.0, 0.0};
   (void)pair;
   double *dev = pair_dev_;
-  if (comm_->device_collectives())
+  if (peers_ok_)
+    check(abft_hip_allreduce_pair_peers(ctx_, dev), "abft_hip_allreduce_pair_peers");
+  else if (comm_->device_collectives())
     comm_->allreduce_sum_device(dev, 2, abft_hip_get_stream(ctx_));
   check(abft_hip_read_pair(ctx_, dev, &v[0], &v[1]), "abft_hip_read_pair");
-  if (!comm_->device_collectives())
+  if (!peers_ok_ && !comm_->device_collectives())
     comm_->allreduce_sum(v, 2);
+  if (std::isnan(v[0]))
+    check_peer_board();
   if (v[1] > 0.0)
     report_events(true);
   return v[0];
@@ -544,7 +658,6 @@ int HIPContextBase::ext_size() { return comm_ ? comm_->size() : 1; }
 void HIPContextBase::fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w, int parity)
 {
   double *cur = fixed_scal_dev_ + 2 * parity, *nxt = fixed_scal_dev_ + 2 * (1 - parity), *pw = fixed_scal_dev_ + 4;
-  void *stream = abft_hip_get_stream(ctx_);
   if (comm_)
   {
     const int off = comm_->rank() * slot_;
@@ -556,10 +669,7 @@ void HIPContextBase::fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, c
     check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw,
                                      overlap_ ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
           "abft_hip_spmv_dot_part_dev");
-    if (comm_->device_collectives())
-      comm_->allreduce_sum_device(pw, 2, stream);
-    else
-      staged_allreduce(pw);
+    device_allreduce(pw);
   }
   else
     check(abft_hip_spmv_dot_dev(ctx_, A->handle, p->handle, w->handle, 0, pw), "abft_hip_spmv_dot_dev");
@@ -567,10 +677,7 @@ void HIPContextBase::fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, c
         "abft_hip_calc_xr_ratio_dev");
   if (comm_)
   {
-    if (comm_->device_collectives())
-      comm_->allreduce_sum_device(nxt, 2, stream);
-    else
-      staged_allreduce(nxt);
+    device_allreduce(nxt);
   }
   check(abft_hip_calc_p_ratio_dev(ctx_, p->handle, r->handle, nxt, cur), "abft_hip_calc_p_ratio_dev");
 }
@@ -598,13 +705,9 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
   copy_vector(r, b);
   copy_vector(p, r);
   check(abft_hip_dot_dev(ctx_, r->handle, r->handle, fixed_scal_dev_), "abft_hip_dot_dev");
-  void *stream = abft_hip_get_stream(ctx_);
   if (comm_)
   {
-    if (comm_->device_collectives())
-      comm_->allreduce_sum_device(fixed_scal_dev_, 2, stream);
-    else
-      staged_allreduce(fixed_scal_dev_);
+    device_allreduce(fixed_scal_dev_);
   }
   // Replay: the iteration is captured once per parity (the rr pairs swap roles) and launched as
   // a graph -- kernels, the exchange and both all-reduces are graph nodes.  Not with host-staged
@@ -671,6 +774,7 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     done++;
   }
   check(abft_hip_synchronize(ctx_), "abft_hip_synchronize");
+  if (comm_) check_peer_board();
   if (comm_) comm_->barrier();
   double dt = timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0 : 0.0;
   if (comm_)

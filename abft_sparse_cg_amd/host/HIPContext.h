@@ -90,6 +90,9 @@ public:
 private:
   void adopt_plan(cg_matrix *M, const ShardPlan &plan);
   void staged_allreduce(double *dev_pair);
+  void setup_peer_board();                 // the node-local all-reduce of the two scalars (abft_hip_peer_board_*)
+  void device_allreduce(double *dev_pair); // {value, events} summed over ranks, enqueue-only where possible
+  void check_peer_board();                 // an all-reduce that gave up waiting ends the job, loudly
   void fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w, int parity);
   void check(int rc, const char *what);
   void report_events(bool force);
@@ -119,6 +122,9 @@ private:
   double *fixed_scal_dev_;
   abft_hip_graph *fixed_graph_[2];
   bool replayed_[2];             // the graph of that parity has completed a replay
+  void *board_map_;              // shared mapping behind the peer board (NULL: not in use)
+  size_t board_bytes_;
+  bool peers_ok_;                // every rank attached the board and it summed correctly
 };
 
 template<int FORMAT, int MODE>

@@ -219,6 +219,22 @@ int abft_hip_read_pair(abft_hip_ctx *ctx, const double *dev_pair, double *value,
 /* ... and the other way (a sum formed on the host, e.g. by host-staged collectives). */
 int abft_hip_write_pair(abft_hip_ctx *ctx, double *dev_pair, double value, double events);
 
+/* All-reduce of such a pair across the processes of ONE node without a collective
+ * library (no counterpart in the reference, which is single-process; SURVEY 8e names the
+ * two scalar all-reduces per iteration).  `shared` is a page-aligned region of at least
+ * abft_hip_peer_board_bytes() that every process of the job has mapped (POSIX shared
+ * memory, zero-filled when created); attach registers it with the GPU.  The all-reduce is
+ * one small kernel on the context's stream -- capturable -- in which each rank publishes
+ * its pair on the board and adds all ranks' pairs in rank order (identical bits everywhere).
+ * Every rank must enqueue the same sequence of all-reduces.  A rank that waits longer than
+ * `timeout_seconds` (<= 0: 120) for a peer leaves NaN and abft_hip_peer_board_failed() = 1. */
+size_t abft_hip_peer_board_bytes(void);
+int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, int rank, int size,
+                               double timeout_seconds);
+int abft_hip_peer_board_detach(abft_hip_ctx *ctx);
+int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair);
+int abft_hip_peer_board_failed(abft_hip_ctx *ctx);
+
 /* Device-scalar forms, for loops that keep alpha and beta on the device (no host
  * round trip per iteration; the row-partitioned solver's fixed-iteration loop):
  *   spmv_dot_dev        result = A vec, and dev_result = {sum_row vec[vec_offset+row]

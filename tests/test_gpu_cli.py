@@ -152,10 +152,10 @@ def hex_history(stderr):
     return hist
 
 
-def run_ranks(world, args, opts=(), fmt="csr"):
+def run_ranks(world, args, opts=(), fmt="csr", env=None):
     cmd = [os.path.join(HOST, "mgpu-run"), str(world)] + list(opts) + ["--", exe(fmt)] + args
     # world 1: still the partitioned code path, with the device collectives on RCCL
-    env = dict(os.environ, ABFT_HIP_VERBOSE="1", ABFT_CG_HEX="1")
+    env = dict(os.environ, ABFT_HIP_VERBOSE="1", ABFT_CG_HEX="1", **(env or {}))
     env.setdefault("ABFT_CG_OVERLAP_BYTES", "0")  # interior rows beside the exchange at any exchange size
     if world == 1:
         env["ABFT_COMM_FORCE"] = "1"
@@ -288,6 +288,23 @@ def test_cpp_coo_driver_column_partitioned(world, mode, flip):
     assert norm(rest1) == norm(restn)
     notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
     assert len(notes) == world and all(" columns [" in l for l in notes)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "coo"])
+def test_scalar_allreduces_over_the_peer_board_equal_the_collective_layer(fmt):
+    """default: the two scalar all-reduces of an iteration go over the board in shared host memory
+    (abft_hip_peer_board_*), here with three processes on the one GPU; ABFT_COMM_ALLREDUCE=tcp keeps
+    them on the host layer.  Both add in rank order: the same bits, iteration by iteration."""
+    args = ["-f", MTX, "-t", "hip", "-m", "secded", "--flip-at", "1234:70"]
+    board = run_ranks(3, args, ("--one-gpu",), fmt=fmt)
+    layer = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "tcp"})
+    assert board.returncode == 0 and layer.returncode == 0, board.stderr[-800:] + layer.stderr[-800:]
+    assert "scalar all-reduces over the peer board (3 ranks" in board.stderr
+    assert "peer board" not in layer.stderr
+    hb, hl = hex_history(board.stderr), hex_history(layer.stderr)
+    assert len(hb) > 50 and hb == hl
+    strip = lambda t: re.sub(r"time taken = .*", "", t)  # noqa: E731
+    assert strip(board.stdout) == strip(layer.stdout) and "corrected bit" in board.stdout
 
 
 def test_run_tests_script_passes_column_partitioned_coo():
