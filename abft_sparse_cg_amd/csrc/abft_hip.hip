@@ -91,6 +91,14 @@ struct abft_hip_ctx {
     int rank = 0, size = 0;
     unsigned long long timeout_ticks = 0;
   } peers;
+  // window exchange over shared host memory (abft_hip_peer_exchange_attach)
+  struct {
+    void *host = nullptr;
+    PeerExchange *dev = nullptr;            // the description the kernel reads
+    unsigned long long *counter = nullptr;  // device: sequence number of the last exchange
+    int rank = 0;
+    size_t extent = 0;                      // doubles of the gathered vector the windows reach
+  } xchg;
 };
 
 struct abft_hip_matrix {
@@ -280,6 +288,7 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipFree(ctx->moved.count);
   (void)hipFree(ctx->bits_dev);
   (void)abft_hip_peer_board_detach(ctx);
+  (void)abft_hip_peer_exchange_detach(ctx);
   (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return ABFT_OK;
@@ -1332,6 +1341,105 @@ extern "C" int abft_hip_peer_board_failed(abft_hip_ctx *ctx) {
   const volatile uint32_t *fail =
       reinterpret_cast<const volatile uint32_t *>(static_cast<PeerSlot *>(ctx->peers.host) + 2 * ABFT_PEER_MAX_RANKS);
   return fail[ctx->peers.rank] != 0;
+}
+
+// ---- window exchange across the processes of one node, through shared host memory ----
+
+static size_t peer_box_bytes(size_t outbox_bytes) { return (outbox_bytes + 255) & ~(size_t)255; }
+
+extern "C" size_t abft_hip_peer_exchange_bytes(int size, size_t outbox_bytes) {
+  if (size < 1) size = 1;
+  return (ABFT_PEER_XHDR_BYTES + (size_t)size * 2u * peer_box_bytes(outbox_bytes) + 4095) & ~(size_t)4095;
+}
+
+extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, int rank, int size,
+                                             size_t outbox_bytes, const abft_peer_piece *out, int nout,
+                                             const abft_peer_piece *in, int nin, double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!shared || ((uintptr_t)shared & 4095u) || bytes < abft_hip_peer_exchange_bytes(size, outbox_bytes))
+    return set_err(ABFT_ERR_INVALID, "peer exchange: a page-aligned mapping of at least %zu bytes is needed",
+                   abft_hip_peer_exchange_bytes(size, outbox_bytes));
+  if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
+    return set_err(ABFT_ERR_RANGE, "peer exchange: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
+  if (nout < 0 || nin < 0 || nout > ABFT_PEER_MAX_PIECES || nin > ABFT_PEER_MAX_PIECES || (nout && !out) || (nin && !in))
+    return set_err(ABFT_ERR_RANGE, "peer exchange: at most %d windows each way", ABFT_PEER_MAX_PIECES);
+  if (ctx->xchg.host) return set_err(ABFT_ERR_INVALID, "peer exchange: already attached");
+  const size_t box = peer_box_bytes(outbox_bytes);
+  size_t extent = 0;
+  PeerExchange X{};
+  X.rank = rank; X.size = size; X.nout = nout; X.nin = nin; X.box_bytes = box;
+  for (int k = 0; k < nout + nin; k++) {
+    const abft_peer_piece &p = k < nout ? out[k] : in[k - nout];
+    // a window must lie inside its outbox (8-byte aligned) and name another rank
+    if (p.peer < 0 || p.peer >= size || p.peer == rank || (p.box_offset & 7u) || p.box_offset > box ||
+        (size_t)p.count * sizeof(double) > box - p.box_offset)
+      return set_err(ABFT_ERR_RANGE, "peer exchange: window %d (peer %d, %u doubles at byte %llu of an outbox of %zu) "
+                     "does not fit", k, p.peer, p.count, (unsigned long long)p.box_offset, box);
+    PeerPiece &d = k < nout ? X.out[k] : X.in[k - nout];
+    extent = std::max(extent, (size_t)p.vector_offset + p.count);
+    d.box_off = p.box_offset; d.vec_off = p.vector_offset; d.count = p.count; d.peer = p.peer; d.pad = 0;
+  }
+  if (hipHostRegister(shared, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(ABFT_ERR_HIP, "peer exchange: hipHostRegister of the shared mapping failed");
+  }
+  void *alias = nullptr;
+  PeerExchange *dev = nullptr;
+  unsigned long long *counter = nullptr;
+  if (hipHostGetDevicePointer(&alias, shared, 0) != hipSuccess || hipMalloc((void **)&dev, sizeof(X)) != hipSuccess ||
+      hipMalloc((void **)&counter, sizeof(*counter)) != hipSuccess ||
+      hipMemsetAsync(counter, 0, sizeof(*counter), ctx->stream) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(shared);
+    (void)hipFree(dev);
+    (void)hipFree(counter);
+    (void)hipGetLastError();
+    return set_err(ABFT_ERR_HIP, "peer exchange: no device view of the shared mapping");
+  }
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+  X.shared = static_cast<unsigned char *>(alias);
+  X.counter = counter;
+  X.timeout_ticks = (unsigned long long)((timeout_seconds > 0 ? timeout_seconds : 120.0) * 1e3 * khz);
+  HIPCHK(hipMemcpyAsync(dev, &X, sizeof(X), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // `X` is on the stack
+  ctx->xchg.host = shared;
+  ctx->xchg.dev = dev;
+  ctx->xchg.counter = counter;
+  ctx->xchg.rank = rank;
+  ctx->xchg.extent = extent;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx) {
+  if (!ctx || !ctx->xchg.host) return ABFT_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipHostUnregister(ctx->xchg.host);
+  (void)hipFree(ctx->xchg.dev);
+  (void)hipFree(ctx->xchg.counter);
+  (void)hipGetLastError();
+  ctx->xchg = {};
+  return ABFT_OK;
+}
+
+// the windows of `full` (a gathered vector of this context) exchanged with the peers, enqueue-only
+extern "C" int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full) {
+  if (int rc = bind(ctx)) return rc;
+  if (!full) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (!ctx->xchg.host) return set_err(ABFT_ERR_INVALID, "peer exchange: not attached");
+  if (full->ctx != ctx || (size_t)full->n < ctx->xchg.extent)
+    return set_err(ABFT_ERR_RANGE, "peer exchange: the windows reach %zu doubles, the vector holds %d", ctx->xchg.extent,
+                   full->n);
+  HIPCHK(launch_peer_exchange(ctx->xchg.dev, full->d, ctx->stream));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx) {
+  if (!ctx || !ctx->xchg.host) return 0;
+  const volatile uint32_t *fail = reinterpret_cast<const volatile uint32_t *>(
+      static_cast<unsigned char *>(ctx->xchg.host) + 2 * ABFT_PEER_MAX_RANKS * sizeof(unsigned long long));
+  return fail[ctx->xchg.rank] != 0;
 }
 
 // ---- device-scalar forms: alpha and beta never leave the GPU -------------------

@@ -275,6 +275,25 @@ struct PeerSlot {
   unsigned long long v0, v1, seq, pad;
 };
 #define ABFT_PEER_BOARD_BYTES (2 * ABFT_PEER_MAX_RANKS * sizeof(PeerSlot) + ABFT_PEER_MAX_RANKS * sizeof(uint32_t))
+// window exchange over shared host memory (see kernels.hip, peer_exchange_kernel): a 4 KB header
+// -- ready[rank], done[rank] sequence numbers, fail[rank] -- then per rank two outboxes (parity)
+#define ABFT_PEER_MAX_PIECES 63
+#define ABFT_PEER_XHDR_BYTES 4096
+struct PeerPiece {
+  unsigned long long box_off;  // bytes from the start of the SENDER's outbox
+  unsigned int vec_off;        // doubles from the start of the gathered vector (this rank's copy)
+  unsigned int count;          // doubles
+  int peer;                    // out: who reads it; in: whose outbox it sits in
+  int pad;
+};
+struct PeerExchange {  // lives in device memory
+  unsigned char *shared;       // device alias of the mapping
+  unsigned long long *counter; // sequence number of the last exchange
+  int rank, size, nout, nin;
+  unsigned long long box_bytes, timeout_ticks;
+  PeerPiece out[ABFT_PEER_MAX_PIECES], in[ABFT_PEER_MAX_PIECES];
+};
+hipError_t launch_peer_exchange(const PeerExchange *X, double *full, hipStream_t s);
 hipError_t launch_peer_allreduce(double *pair, PeerSlot *board, unsigned long long *counter, uint32_t *fail, int rank,
                                  int size, unsigned long long timeout_ticks, hipStream_t s);
 hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s);

@@ -1924,6 +1924,80 @@ hipError_t launch_peer_allreduce(double *pair, PeerSlot *board, unsigned long lo
   return hipGetLastError();
 }
 
+// ------------------------------------------ window exchange over shared host memory --
+//
+// The halo of a banded matrix in front of a row-partitioned SpMV (a few KB to a few hundred
+// KB per neighbour) between the processes of one node, in ONE kernel: every rank copies the
+// windows its peers read out of its slot of the gathered vector into its outbox in shared
+// host memory, publishes the sequence number, waits for the ranks it reads from and copies
+// their windows into its own gathered vector.  Outboxes are doubled by the parity of the
+// sequence number; before a rank overwrites an outbox it waits until its readers have
+// finished with the exchange two back (`done`), so the protocol does not lean on whatever
+// else synchronises the ranks in between.  Capturable, bounded waits, NaN + flag on give-up.
+__device__ __forceinline__ bool peer_wait_ge(const unsigned long long *word, unsigned long long want,
+                                             unsigned long long timeout_ticks) {
+  const unsigned long long t0 = (unsigned long long)wall_clock64();
+  while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+    if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) return false;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange *Xp, double *__restrict__ full) {
+  __shared__ uint32_t s_bad;
+  const PeerExchange &X = *Xp;
+  const uint32_t t = threadIdx.x;
+  const unsigned long long seq = *X.counter + 1ull;
+  const unsigned long long q = seq & 1ull;
+  unsigned long long *ready = reinterpret_cast<unsigned long long *>(X.shared);
+  unsigned long long *done = ready + ABFT_PEER_MAX_RANKS;
+  uint32_t *fail = reinterpret_cast<uint32_t *>(done + ABFT_PEER_MAX_RANKS);
+  if (t == 0) s_bad = 0u;
+  __syncthreads();
+  // the readers of the outbox about to be overwritten are through with exchange seq - 2
+  if (t < (uint32_t)X.nout && seq > 2ull && !peer_wait_ge(done + X.out[t].peer, seq - 2ull, X.timeout_ticks))
+    atomicOr(&s_bad, 1u);
+  __syncthreads();
+  unsigned char *mybox = X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)X.rank * 2u + q) * X.box_bytes;
+  for (int k = 0; k < X.nout; k++) {
+    const PeerPiece pc = X.out[k];
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(mybox + pc.box_off);
+    const double *src = full + pc.vec_off;
+    for (uint32_t i = t; i < pc.count; i += 1024u)
+      __hip_atomic_store(dst + i, (unsigned long long)__double_as_longlong(src[i]), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t == 0) __hip_atomic_store(ready + X.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (t < (uint32_t)X.nin && !peer_wait_ge(ready + X.in[t].peer, seq, X.timeout_ticks)) atomicOr(&s_bad, 1u);
+  __syncthreads();
+  const bool bad = s_bad != 0u;
+  for (int k = 0; k < X.nin && !bad; k++) {
+    const PeerPiece pc = X.in[k];
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
+        X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)pc.peer * 2u + q) * X.box_bytes + pc.box_off);
+    double *dst = full + pc.vec_off;
+    for (uint32_t i = t; i < pc.count; i += 1024u)
+      dst[i] = __longlong_as_double((long long)__hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  }
+  __syncthreads();
+  if (t == 0) {
+    if (bad) {
+      if (X.nin > 0) full[X.in[0].vec_off] = __longlong_as_double(0x7ff8000000000000ll);
+      __hip_atomic_store(fail + X.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __hip_atomic_store(done + X.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    *X.counter = seq;
+  }
+}
+
+hipError_t launch_peer_exchange(const PeerExchange *X, double *full, hipStream_t s) {
+  hipLaunchKernelGGL(peer_exchange_kernel, dim3(1), dim3(1024), 0, s, X, full);
+  return hipGetLastError();
+}
+
 // copy_vector (reference CSR/CPUContext.cpp:76-80: memcpy of dst->N doubles), as an
 // ordinary kernel on the context's stream (capturable; no runtime copy path involved)
 template <int VEC>

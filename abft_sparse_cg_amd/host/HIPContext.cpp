@@ -18,7 +18,8 @@
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
     r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
-    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false)
+    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false),
+    one_node_(false), xchg_map_(NULL), xchg_bytes_(0), peer_xchg_ok_(false)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
   replayed_[0] = replayed_[1] = false;
@@ -38,6 +39,56 @@ HIPContextBase::HIPContextBase(int format, int mode)
   }
 }
 
+// One zero-filled shared-memory object of `bytes`, created by rank 0 and mapped by every rank
+// (unlinked again once all have it: nothing stays behind in /dev/shm).  NULL on this rank if
+// anything failed here or on rank 0; the callers agree on the outcome with all_ranks().
+void *HIPContextBase::shared_region(size_t bytes)
+{
+  const int rank = comm_->rank();
+  char name[96];
+  memset(name, 0, sizeof(name));
+  int fd = -1;
+  if (rank == 0 && one_node_)
+  {
+    static int serial = 0;
+    snprintf(name, sizeof(name), "/abft_cg_%ld_%d_%lld", (long)getpid(), serial++,
+             (long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)bytes) != 0)  // (a fresh object reads as zeros)
+    {
+      if (fd >= 0) { close(fd); shm_unlink(name); fd = -1; }
+      name[0] = 0;
+    }
+  }
+  comm_->bcast(name, sizeof(name), 0);
+  if (name[0] && rank != 0)
+    fd = shm_open(name, O_RDWR, 0);
+  void *map = MAP_FAILED;
+  if (name[0] && fd >= 0)
+    map = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  if (fd >= 0)
+    close(fd);
+  comm_->barrier();  // everybody who could has mapped it
+  if (rank == 0 && name[0])
+    shm_unlink(name);
+  return map == MAP_FAILED ? NULL : map;
+}
+
+bool HIPContextBase::all_ranks(bool mine)
+{
+  double v = mine ? 1.0 : 0.0;
+  comm_->allreduce_sum(&v, 1);
+  return v == (double)comm_->size();
+}
+
+static double comm_timeout_seconds()
+{
+  double timeout = 120.0;
+  if (const char *t = getenv("ABFT_COMM_TIMEOUT"))
+    timeout = atof(t) > 0 ? atof(t) : timeout;
+  return timeout;
+}
+
 // The two scalar all-reduces of an iteration go over a board in shared host memory when all
 // ranks sit on one node (they do: one process per GPU of a node): one small kernel each, no
 // collective library in the iteration's critical path.  ABFT_COMM_ALLREDUCE=rccl (or tcp) keeps
@@ -45,52 +96,22 @@ HIPContextBase::HIPContextBase(int format, int mode)
 // test sums came out right, else the collective layer -- decided together, so all ranks agree.
 void HIPContextBase::setup_peer_board()
 {
-  const char *env = getenv("ABFT_COMM_ALLREDUCE");
-  if (env && strcmp(env, "board") && strcmp(env, "auto"))
-    return;
   const int size = comm_->size(), rank = comm_->rank();
   char host[64];
   memset(host, 0, sizeof(host));
   gethostname(host, sizeof(host) - 1);
   std::vector<char> hosts((size_t)size * sizeof(host));
   comm_->allgather(host, sizeof(host), hosts.data());
-  bool one_node = true;
+  one_node_ = size <= 64;
   for (int r = 0; r < size; r++)
-    one_node = one_node && !memcmp(&hosts[(size_t)r * sizeof(host)], host, sizeof(host));
+    one_node_ = one_node_ && !memcmp(&hosts[(size_t)r * sizeof(host)], host, sizeof(host));
+  const char *env = getenv("ABFT_COMM_ALLREDUCE");
+  if (env && strcmp(env, "board") && strcmp(env, "auto"))
+    return;
   board_bytes_ = abft_hip_peer_board_bytes();
-  char name[96];
-  memset(name, 0, sizeof(name));
-  int fd = -1;
-  if (rank == 0 && one_node && size <= 64)
-  {
-    snprintf(name, sizeof(name), "/abft_cg_board_%ld_%lld", (long)getpid(),
-             (long long)std::chrono::steady_clock::now().time_since_epoch().count());
-    fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
-    if (fd < 0 || ftruncate(fd, (off_t)board_bytes_) != 0)  // (a fresh object reads as zeros)
-    {
-      if (fd >= 0) { close(fd); shm_unlink(name); fd = -1; }
-      name[0] = 0;
-    }
-  }
-  comm_->bcast(name, sizeof(name), 0);
-  bool ok = name[0] != 0;
-  if (ok && rank != 0)
-    fd = shm_open(name, O_RDWR, 0);
-  void *map = MAP_FAILED;
-  if (ok && fd >= 0)
-    map = mmap(NULL, board_bytes_, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  if (fd >= 0)
-    close(fd);
-  ok = ok && map != MAP_FAILED;
-  double timeout = 120.0;
-  if (const char *t = getenv("ABFT_COMM_TIMEOUT"))
-    timeout = atof(t) > 0 ? atof(t) : timeout;
-  bool attached = ok && abft_hip_peer_board_attach(ctx_, map, board_bytes_, rank, size, timeout) == ABFT_OK;
-  double agree = attached ? 1.0 : 0.0;
-  comm_->allreduce_sum(&agree, 1);  // also: everybody has mapped the object by now
-  if (rank == 0 && name[0])
-    shm_unlink(name);
-  bool all = agree == (double)size;
+  void *map = shared_region(board_bytes_);
+  const bool attached = map && abft_hip_peer_board_attach(ctx_, map, board_bytes_, rank, size, comm_timeout_seconds()) == ABFT_OK;
+  bool all = all_ranks(attached);
   for (int t = 0; t < 3 && all; t++)
   {
     // {rank + 1 + t, 1} summed over ranks
@@ -98,16 +119,13 @@ void HIPContextBase::setup_peer_board()
     check(abft_hip_allreduce_pair_peers(ctx_, pair_dev_), "abft_hip_allreduce_pair_peers");
     double v = 0.0, e = 0.0;
     check(abft_hip_read_pair(ctx_, pair_dev_, &v, &e), "abft_hip_read_pair");
-    const bool right = v == 0.5 * size * (size + 1) + (double)t * size && e == (double)size;
-    agree = right ? 1.0 : 0.0;
-    comm_->allreduce_sum(&agree, 1);
-    all = agree == (double)size;
+    all = all_ranks(v == 0.5 * size * (size + 1) + (double)t * size && e == (double)size);
   }
   if (!all)
   {
     if (attached)
       abft_hip_peer_board_detach(ctx_);
-    if (map != MAP_FAILED)
+    if (map)
       munmap(map, board_bytes_);
     if (env && !strcmp(env, "board"))
     {
@@ -122,8 +140,108 @@ void HIPContextBase::setup_peer_board()
     fprintf(stderr, "hip backend: scalar all-reduces over the peer board (%d ranks, %s)\n", size, host);
 }
 
+// The halo windows of a banded matrix travel through shared host memory too, in one kernel per
+// exchange (abft_hip_peer_exchange): decided per matrix from the windows every rank already knows
+// (all_need_), so all ranks lay the outboxes out alike without talking.  ABFT_COMM_EXCHANGE=rccl
+// (or tcp) keeps the collective layer; ABFT_COMM_WINDOW_BYTES caps an outbox (default 1 MiB:
+// beyond that the copy through host memory costs more than a collective's latency).
+void HIPContextBase::setup_peer_exchange()
+{
+  if (peer_xchg_ok_)
+  {
+    abft_hip_peer_exchange_detach(ctx_);
+    munmap(xchg_map_, xchg_bytes_);
+    xchg_map_ = NULL;
+    peer_xchg_ok_ = false;
+  }
+  const char *env = getenv("ABFT_COMM_EXCHANGE");
+  if (env && strcmp(env, "board") && strcmp(env, "auto"))
+    return;
+  const int G = comm_->size(), me = comm_->rank();
+  if (!one_node_ || !use_windows_ || G < 2)
+    return;
+  // every sender's outbox: its windows in ascending reader order, 256-byte aligned
+  std::vector<abft_peer_piece> out, in;
+  size_t box = 0;
+  for (int g = 0; g < G; g++)
+  {
+    size_t off = 0;
+    for (int q = 0; q < G; q++)
+    {
+      if (q == g) continue;
+      const int *w = &all_need_[2 * ((size_t)q * G + g)];  // what rank q reads of rank g's slot
+      if (w[1] <= w[0]) continue;
+      abft_peer_piece pc;
+      pc.count = (uint32_t)(w[1] - w[0]);
+      pc.vector_offset = (uint32_t)((size_t)g * slot_ + w[0]);
+      pc.box_offset = off;
+      if (g == me) { pc.peer = q; out.push_back(pc); }
+      if (q == me) { pc.peer = g; in.push_back(pc); }
+      off += ((size_t)pc.count * sizeof(double) + 255) & ~(size_t)255;
+    }
+    box = std::max(box, off);
+  }
+  long long cap = 1ll << 20;
+  if (const char *c = getenv("ABFT_COMM_WINDOW_BYTES")) cap = atoll(c);
+  if (box == 0 || (long long)box > cap)
+    return;
+  xchg_bytes_ = abft_hip_peer_exchange_bytes(G, box);
+  void *map = shared_region(xchg_bytes_);
+  const bool attached = map && abft_hip_peer_exchange_attach(ctx_, map, xchg_bytes_, me, G, box, out.empty() ? NULL : out.data(),
+                                                             (int)out.size(), in.empty() ? NULL : in.data(), (int)in.size(),
+                                                             comm_timeout_seconds()) == ABFT_OK;
+  bool all = all_ranks(attached);
+  if (all)
+  {
+    // two test exchanges (both outboxes) of a vector whose entry i of slot g holds (g + 1) * 2^26 + i + round
+    abft_hip_vector *probe = NULL;
+    check(abft_hip_vector_create(ctx_, n_pad_, &probe), "abft_hip_vector_create");
+    bool right = true;
+    for (int round = 0; round < 2; round++)
+    {
+      double *h = NULL;
+      check(abft_hip_vector_map(probe, &h), "abft_hip_vector_map");
+      for (int i = 0; i < n_pad_; i++) h[i] = -1.0;
+      for (int i = 0; i < slot_; i++) h[(size_t)me * slot_ + i] = (double)(me + 1) * 67108864.0 + i + round;
+      check(abft_hip_vector_unmap(probe, h), "abft_hip_vector_unmap");
+      check(abft_hip_peer_exchange(ctx_, probe), "abft_hip_peer_exchange");
+      check(abft_hip_vector_map(probe, &h), "abft_hip_vector_map");
+      for (size_t k = 0; k < in.size(); k++)
+        for (uint32_t i = 0; i < in[k].count; i++)
+        {
+          const size_t at = (size_t)in[k].vector_offset + i;
+          right = right && h[at] == (double)(in[k].peer + 1) * 67108864.0 + (double)(at - (size_t)in[k].peer * slot_) + round;
+        }
+      check(abft_hip_vector_unmap(probe, h), "abft_hip_vector_unmap");
+    }
+    abft_hip_vector_destroy(probe);
+    all = all_ranks(right && !abft_hip_peer_exchange_failed(ctx_));
+  }
+  if (!all)
+  {
+    if (attached)
+      abft_hip_peer_exchange_detach(ctx_);
+    if (map)
+      munmap(map, xchg_bytes_);
+    if (env && !strcmp(env, "board"))
+    {
+      fprintf(stderr, "hip backend: ABFT_COMM_EXCHANGE=board, but the exchange could not be set up on every rank\n");
+      exit(2);
+    }
+    return;
+  }
+  xchg_map_ = map;
+  peer_xchg_ok_ = true;
+}
+
 void HIPContextBase::check_peer_board()
 {
+  if (peer_xchg_ok_ && abft_hip_peer_exchange_failed(ctx_))
+  {
+    fflush(stdout);
+    fprintf(stderr, "hip backend: rank %d gave up waiting for a peer in a window exchange (shared memory)\n", comm_->rank());
+    exit(2);
+  }
   if (peers_ok_ && abft_hip_peer_board_failed(ctx_))
   {
     fflush(stdout);
@@ -157,6 +275,8 @@ HIPContextBase::~HIPContextBase()
     abft_hip_shutdown(ctx_);  // (detaches the peer board)
     if (board_map_)
       munmap(board_map_, board_bytes_);
+    if (xchg_map_)
+      munmap(xchg_map_, xchg_bytes_);
   }
   if (comm_)
   {
@@ -359,10 +479,12 @@ void HIPContextBase::adopt_plan(cg_matrix *M, const ShardPlan &plan)
   long long least = 2ll << 20;
   if (const char *env = getenv("ABFT_CG_OVERLAP_BYTES")) least = atoll(env);
   overlap_ = interior && incoming * 8 >= least;
+  setup_peer_exchange();
   if (getenv("ABFT_HIP_VERBOSE"))
     fprintf(stderr, "hip backend: rank %d of %d: %s [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
             "interior rows [%d,%d)%s\n", me, G, format_ == ABFT_FMT_CSR ? "rows" : "columns", r0_, r0_ + n_loc_, cnt,
-            plan.first, use_windows_ ? "windows" : "all-gather", comm_->device_collectives() ? "RCCL" : "TCP",
+            plan.first, use_windows_ ? "windows" : "all-gather",
+            peer_xchg_ok_ ? "shared memory" : comm_->device_collectives() ? "RCCL" : "TCP",
             plan.interior_lo, plan.interior_hi, overlap_ ? " beside the exchange" : "");
 }
 
@@ -494,6 +616,11 @@ void HIPContextBase::calc_p(cg_vector *p, const cg_vector *r, double beta)
 // the host (ABFT_COMM=tcp) it is synchronous and happens in finish, i.e. strictly after.
 void HIPContextBase::exchange_begin(cg_vector *v)
 {
+  if (peer_xchg_ok_)
+  {
+    check(abft_hip_peer_exchange(ctx_, v->full), "abft_hip_peer_exchange");
+    return;
+  }
   if (!comm_->device_collectives())
     return;
   const int G = comm_->size(), me = comm_->rank();
@@ -521,6 +648,8 @@ void HIPContextBase::exchange_begin(cg_vector *v)
 
 void HIPContextBase::exchange_finish(cg_vector *v)
 {
+  if (peer_xchg_ok_)
+    return;
   if (comm_->device_collectives())
   {
     comm_->device_exchange_finish(abft_hip_get_stream(ctx_));
@@ -714,7 +843,7 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
   // collectives (they synchronise).  ABFT_CG_GRAPH=0 keeps the eager enqueue.  The first two
   // iterations always run eagerly: communicators and peer connections are set up by their first
   // use, which must not happen under capture.
-  bool graph = !(comm_ && !comm_->device_collectives());
+  bool graph = !comm_ || comm_->device_collectives() || (peers_ok_ && peer_xchg_ok_);
   if (const char *env = getenv("ABFT_CG_GRAPH")) graph = graph && strcmp(env, "0") != 0;
   int done = 0;
   const int total = warmup + steps;

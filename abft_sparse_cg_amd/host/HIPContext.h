@@ -90,6 +90,9 @@ public:
 private:
   void adopt_plan(cg_matrix *M, const ShardPlan &plan);
   void staged_allreduce(double *dev_pair);
+  void *shared_region(size_t bytes);       // collective: one zero-filled POSIX shared-memory object mapped by every rank
+  bool all_ranks(bool mine);               // collective: true if true on every rank
+  void setup_peer_exchange();              // halo windows through shared host memory (abft_hip_peer_exchange_*)
   void setup_peer_board();                 // the node-local all-reduce of the two scalars (abft_hip_peer_board_*)
   void device_allreduce(double *dev_pair); // {value, events} summed over ranks, enqueue-only where possible
   void check_peer_board();                 // an all-reduce that gave up waiting ends the job, loudly
@@ -125,6 +128,10 @@ private:
   void *board_map_;              // shared mapping behind the peer board (NULL: not in use)
   size_t board_bytes_;
   bool peers_ok_;                // every rank attached the board and it summed correctly
+  bool one_node_;                // every rank runs on this host
+  void *xchg_map_;               // shared mapping behind the window exchange (NULL: not in use)
+  size_t xchg_bytes_;
+  bool peer_xchg_ok_;            // the windows of this matrix travel through shared host memory
 };
 
 template<int FORMAT, int MODE>

@@ -235,6 +235,31 @@ int abft_hip_peer_board_detach(abft_hip_ctx *ctx);
 int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair);
 int abft_hip_peer_board_failed(abft_hip_ctx *ctx);
 
+/* The windows of the gathered vector that a rank's peers read (the halo of a banded matrix)
+ * exchanged between the processes of ONE node through shared host memory, in one capturable
+ * kernel on the context's stream ("a neighbour exchange would beat an all-gather"
+ * for banded matrices).  `shared`: a page-aligned, zero-filled region of at least
+ * abft_hip_peer_exchange_bytes(size, outbox_bytes) mapped by every process; every rank lays
+ * the windows it sends out in its outbox (`box_offset`, 8-byte aligned, the same
+ * outbox_bytes on every rank) and lists the windows it receives with the offsets their
+ * senders chose.  `vector_offset` / `count` are in doubles from the start of the gathered
+ * vector passed to abft_hip_peer_exchange.  Every rank must enqueue the same sequence of
+ * exchanges.  Give-up after `timeout_seconds` (<= 0: 120): NaN in the first received window
+ * and abft_hip_peer_exchange_failed() = 1. */
+typedef struct {
+  int peer;                 /* out: the rank that reads it; in: the rank that sends it */
+  uint32_t vector_offset;   /* doubles */
+  uint32_t count;           /* doubles */
+  uint64_t box_offset;      /* bytes from the start of the SENDER's outbox */
+} abft_peer_piece;
+size_t abft_hip_peer_exchange_bytes(int size, size_t outbox_bytes);
+int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, int rank, int size,
+                                  size_t outbox_bytes, const abft_peer_piece *out, int nout,
+                                  const abft_peer_piece *in, int nin, double timeout_seconds);
+int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx);
+int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full);
+int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx);
+
 /* Device-scalar forms, for loops that keep alpha and beta on the device (no host
  * round trip per iteration; the row-partitioned solver's fixed-iteration loop):
  *   spmv_dot_dev        result = A vec, and dev_result = {sum_row vec[vec_offset+row]

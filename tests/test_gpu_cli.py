@@ -201,7 +201,8 @@ def test_cpp_driver_row_partitioned(world, opts, mode, flip):
     notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
     assert len(notes) == world
     if world > 1:
-        assert all("exchange by windows over TCP" in l and "interior rows [0,0)" not in l and
+        # (the windows themselves: through shared host memory, one kernel per exchange)
+        assert all("exchange by windows over shared memory" in l and "interior rows [0,0)" not in l and
                    l.endswith("beside the exchange") for l in notes)
     else:
         assert "over RCCL" in notes[0]
@@ -293,14 +294,16 @@ def test_cpp_coo_driver_column_partitioned(world, mode, flip):
 @pytest.mark.parametrize("fmt", ["csr", "coo"])
 def test_scalar_allreduces_over_the_peer_board_equal_the_collective_layer(fmt):
     """default: the two scalar all-reduces of an iteration go over the board in shared host memory
-    (abft_hip_peer_board_*), here with three processes on the one GPU; ABFT_COMM_ALLREDUCE=tcp keeps
+    (abft_hip_peer_board_*) and the halo windows through outboxes there (abft_hip_peer_exchange_*),
+    here with three processes on the one GPU; ABFT_COMM_ALLREDUCE=tcp / ABFT_COMM_EXCHANGE=tcp keep
     them on the host layer.  Both add in rank order: the same bits, iteration by iteration."""
     args = ["-f", MTX, "-t", "hip", "-m", "secded", "--flip-at", "1234:70"]
     board = run_ranks(3, args, ("--one-gpu",), fmt=fmt)
-    layer = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "tcp"})
+    layer = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "tcp", "ABFT_COMM_EXCHANGE": "tcp"})
     assert board.returncode == 0 and layer.returncode == 0, board.stderr[-800:] + layer.stderr[-800:]
     assert "scalar all-reduces over the peer board (3 ranks" in board.stderr
-    assert "peer board" not in layer.stderr
+    assert board.stderr.count("exchange by windows over shared memory") == 3
+    assert "peer board" not in layer.stderr and layer.stderr.count("exchange by windows over TCP") == 3
     hb, hl = hex_history(board.stderr), hex_history(layer.stderr)
     assert len(hb) > 50 and hb == hl
     strip = lambda t: re.sub(r"time taken = .*", "", t)  # noqa: E731

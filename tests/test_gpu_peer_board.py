@@ -107,3 +107,85 @@ def test_attach_refuses_bad_arguments(pair_of_contexts):
     assert read_pair(L, capi, c, pairs[0]) == (7.25, 2.0)
     capi.check(L.abft_hip_peer_board_detach(c.h))
     capi.check(L.abft_hip_peer_board_detach(c.h))
+
+
+# ---- window exchange (abft_hip_peer_exchange_*) ----
+
+class Piece(C.Structure):
+    _fields_ = [("peer", C.c_int), ("vector_offset", C.c_uint32), ("count", C.c_uint32), ("box_offset", C.c_uint64)]
+
+
+def pieces(items):
+    arr = (Piece * max(1, len(items)))()
+    for a, (peer, voff, count, boff) in zip(arr, items):
+        a.peer, a.vector_offset, a.count, a.box_offset = peer, voff, count, boff
+    return arr
+
+
+@pytest.fixture()
+def two_ranks_with_outboxes():
+    import abft_sparse_cg_amd as amd
+    from abft_sparse_cg_amd import capi
+    L = capi.load()
+    box = 3 * 4096  # bytes per outbox
+    nbytes = L.abft_hip_peer_exchange_bytes(2, box)
+    fd = os.memfd_create("abft_xchg_test")
+    os.ftruncate(fd, nbytes)
+    maps = [mmap.mmap(fd, nbytes), mmap.mmap(fd, nbytes)]
+    os.close(fd)
+    addr = [C.addressof(C.c_char.from_buffer(m)) for m in maps]
+    ctxs = [amd.HIPContext("none", "csr"), amd.HIPContext("none", "csr")]
+    yield L, capi, ctxs, addr, nbytes, box
+    for c in ctxs:
+        c.close()
+
+
+def test_windows_travel_both_ways_round_after_round(two_ranks_with_outboxes):
+    L, capi, ctxs, addr, nbytes, box = two_ranks_with_outboxes
+    slot = 1000
+    # rank 0 reads [0, 37) and [500, 501) of rank 1's slot; rank 1 reads [990, 1000) of rank 0's
+    out = [pieces([(1, 0 * slot + 990, 10, 0)]), pieces([(0, 1 * slot + 0, 37, 0), (0, 1 * slot + 500, 1, 512)])]
+    inn = [pieces([(1, 1 * slot + 0, 37, 0), (1, 1 * slot + 500, 1, 512)]), pieces([(0, 0 * slot + 990, 10, 0)])]
+    nout, nin = [1, 2], [2, 1]
+    for r, c in enumerate(ctxs):
+        capi.check(L.abft_hip_peer_exchange_attach(c.h, addr[r], nbytes, r, 2, box, out[r], nout[r], inn[r], nin[r], 20.0))
+    full = [c.create_vector(2 * slot) for c in ctxs]
+    rng = np.random.default_rng(11)
+    for k in range(5):
+        mine = [rng.standard_normal(slot) for _ in ctxs]
+        before = []
+        for r, (c, v) in enumerate(zip(ctxs, full)):
+            h = np.full(2 * slot, -7.0 - k)
+            h[r * slot:(r + 1) * slot] = mine[r]
+            c.upload(v, h)
+            before.append(h)
+        for c, v in zip(ctxs, full):
+            capi.check(L.abft_hip_peer_exchange(c.h, v.h))
+        got = [c.download(v) for c, v in zip(ctxs, full)]
+        want0, want1 = before[0].copy(), before[1].copy()
+        want0[slot:slot + 37] = mine[1][:37]
+        want0[slot + 500] = mine[1][500]
+        want1[990:1000] = mine[0][990:]
+        assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1), k
+        assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
+
+
+def test_exchange_gives_up_loudly_and_refuses_bad_windows(two_ranks_with_outboxes):
+    L, capi, ctxs, addr, nbytes, box = two_ranks_with_outboxes
+    c = ctxs[0]
+    v = c.create_vector(64)
+    assert L.abft_hip_peer_exchange(c.h, v.h) != 0  # not attached
+    one = pieces([(1, 0, 8, 0)])
+    assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(0, 0, 8, 0)]), 1, one, 1, 1.0) != 0  # to itself
+    assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, 8, 4)]), 1, one, 1, 1.0) != 0  # unaligned
+    assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, box // 8 + 1, 0)]), 1, one, 1, 1.0) != 0
+    assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes - 4096, 0, 2, box, one, 1, one, 1, 1.0) != 0
+    capi.check(L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, 8, 0)]), 1,
+                                               pieces([(1, 32, 8, 0)]), 1, 0.5))
+    small = c.create_vector(16)
+    assert L.abft_hip_peer_exchange(c.h, small.h) != 0  # the windows reach past this vector
+    c.upload(v, np.arange(64.0))
+    capi.check(L.abft_hip_peer_exchange(c.h, v.h))  # rank 1 never shows up
+    got = c.download(v)
+    assert math.isnan(got[32]) and L.abft_hip_peer_exchange_failed(c.h) == 1
+    capi.check(L.abft_hip_peer_exchange_detach(c.h))
