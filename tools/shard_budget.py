@@ -10,19 +10,23 @@ For each world size G and a few ranks k it builds rank k's shard exactly as the 
 host/partition.cpp), and times the iteration's kernels through the C ABI with the scalars
 resident on the device and the iteration replayed as a hipGraph (what host/cg-csr --bench
 runs, minus the collectives):  spmv+dot, calc_xr (r half), calc_p (+x half).
-Measured besides: the host cost of one graph launch, and RCCL's all-reduce of two doubles at
-world size 1 is NOT measured here (see DESIGN.md section 5 for the numbers assumed).
+Measured besides: the host cost of one graph launch.  For G > 1 the replayed iteration also holds
+the two scalar all-reduces as the multi-process host enqueues them -- the peer-board kernel
+(abft_hip_allreduce_pair_peers) on a board of ONE rank: two PCIe crossings and a launch each,
+i.e. what they cost when all peers arrive together; the skew between real ranks is not in it.
 
 Projection per iteration at G ranks:
-    T(G) = max_k kernels(G, k) + T_exchange(G) + 2 * T_allreduce
+    T(G) = max_k kernels(G, k)  [incl. the two board all-reduces]  + T_exchange(G)
     T_exchange = all-gather of 8 * slot bytes per rank over xGMI: each rank receives (G-1) slots,
                  one from each peer over its own link, concurrently: 8 * slot / (LINK_GBPS * EFF)
-                 (banded matrices exchange halo windows of a few KB instead: latency only)
-with LINK_GBPS = 153 (MI355X_MICROARCH.md: 7 links x ~153 GB/s), EFF = 0.7, T_allreduce = 12 us,
-T_latency = 10 us for a windows exchange.  Prints a markdown table (commit it under profiles/)."""
+                 (banded matrices exchange halo windows of a few KB through shared host memory
+                 instead, one kernel: T_WINDOW_US, assumed)
+with LINK_GBPS = 153 (MI355X_MICROARCH.md: 7 links x ~153 GB/s), EFF = 0.7, T_WINDOW_US = 8.
+Prints a markdown table (commit it under profiles/)."""
 import argparse
 import ctypes as C
 import json
+import mmap
 import os
 import sys
 import time
@@ -32,7 +36,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-LINK_GBPS, EFF, T_ALLREDUCE_US, T_WINDOW_US = 153.0, 0.7, 12.0, 10.0
+LINK_GBPS, EFF, T_WINDOW_US = 153.0, 0.7, 8.0
 
 
 def shard(spec, G, k):
@@ -55,7 +59,7 @@ def shard(spec, G, k):
         int(remote.sum()), n
 
 
-def time_shard(mode, pin, lrows, vals, n_loc, n_pad, slot, k, iters=60):
+def time_shard(mode, pin, lrows, vals, n_loc, n_pad, slot, k, iters=60, allreduce=False):
     import abft_sparse_cg_amd as amd
     from abft_sparse_cg_amd import capi
     ctx = amd.HIPContext(mode, "csr", device=0)
@@ -72,10 +76,19 @@ def time_shard(mode, pin, lrows, vals, n_loc, n_pad, slot, k, iters=60):
     ctx.upload(sc, np.array([1.0, 0.0, 1.0, 0.0, 1.0, 0.0]))
     base = sc.device_ptr
 
+    board = None
+    if allreduce:  # a board of one rank: the all-reduce kernel's own cost
+        board = mmap.mmap(-1, L.abft_hip_peer_board_bytes())
+        capi.check(L.abft_hip_peer_board_attach(h, C.addressof(C.c_char.from_buffer(board)), len(board), 0, 1, 5.0))
+
     def it(parity):
         cur, nxt, pw = base + 16 * parity, base + 16 * (1 - parity), base + 32
         capi.check(L.abft_hip_spmv_dot_dev(h, A.h, pfull.h, w.h, k * slot, pw))
+        if allreduce:
+            capi.check(L.abft_hip_allreduce_pair_peers(h, pw))
         capi.check(L.abft_hip_calc_xr_ratio_dev(h, x.h, r.h, p.h, w.h, cur, pw, nxt))
+        if allreduce:
+            capi.check(L.abft_hip_allreduce_pair_peers(h, nxt))
         capi.check(L.abft_hip_calc_p_ratio_dev(h, p.h, r.h, nxt, cur))
     it(0); it(1)
     ctx.synchronize()
@@ -118,7 +131,7 @@ def main():
     for G in [int(v) for v in a.ranks.split(",")]:
         for k in sorted({0, G // 2, G - 1}):
             pin, lrows, vals, n_loc, n_pad, slot, window, remote, n = shard(a.spec, G, k)
-            t = time_shard(a.mode, pin, lrows, vals, n_loc, n_pad, slot, k)
+            t = time_shard(a.mode, pin, lrows, vals, n_loc, n_pad, slot, k, allreduce=G > 1)
             use_windows = G > 1 and window * 2 * G < n * (G - 1)  # this rank's share of the planner's rule
             t.update(G=G, rank=k, rows=int(n_loc), nnz=int(len(vals)), slot=int(slot), window_entries=window,
                      exchange="windows" if use_windows else ("all-gather" if G > 1 else "none"))
@@ -127,29 +140,30 @@ def main():
                   "launch %.1f us of host time)" % (G, k, n_loc, len(vals), t["layout"], t["iter_us"], t["spmv_us"],
                                                     t["host_launch_us"]), flush=True)
     print("\nPROJECTED (assumptions in the module docstring; no multi-GPU run behind it)\n")
-    print("| GPUs | slowest rank's kernels, us (measured, 1 GPU) | exchange, us (assumed) | 2 all-reduces, us (assumed) | "
+    print("| GPUs | slowest rank's kernels incl. the two board all-reduces, us (measured, 1 GPU) | exchange, us (assumed) | "
           "iteration, us | speed-up vs 1 GPU |")
-    print("|---|---|---|---|---|---|")
+    print("|---|---|---|---|---|")
     t1 = None
     out = []
     for G in sorted({r["G"] for r in rows}):
         rs = [r for r in rows if r["G"] == G]
         kern = max(r["iter_us"] for r in rs)
         if G == 1:
-            ex = ar = 0.0
+            ex = 0.0
         elif rs[0]["exchange"] == "windows":
-            ex, ar = T_WINDOW_US, 2 * T_ALLREDUCE_US
+            ex = T_WINDOW_US
         else:
-            ex, ar = 8.0 * rs[0]["slot"] / (LINK_GBPS * EFF * 1e3), 2 * T_ALLREDUCE_US
-        tot = kern + ex + ar
+            ex = 8.0 * rs[0]["slot"] / (LINK_GBPS * EFF * 1e3)
+        tot = kern + ex
         t1 = tot if G == 1 else t1
-        out.append({"G": G, "kernels_us": kern, "exchange_us": ex, "allreduce_us": ar, "iteration_us": tot,
+        out.append({"G": G, "kernels_us": kern, "exchange_us": ex, "iteration_us": tot,
                     "speedup": (t1 / tot) if t1 else None})
-        print("| %d | %.1f | %.1f | %.1f | %.1f | %s |" % (G, kern, ex, ar, tot, ("%.2fx" % (t1 / tot)) if t1 else "-"))
+        print("| %d | %.1f | %.1f | %.1f | %s |" % (G, kern, ex, tot, ("%.2fx" % (t1 / tot)) if t1 else "-"))
     if a.json:
         json.dump({"spec": a.spec, "mode": a.mode, "measured": rows, "projected": out,
-                   "assumptions": {"link_GBps": LINK_GBPS, "efficiency": EFF, "allreduce_us": T_ALLREDUCE_US,
-                                   "window_exchange_us": T_WINDOW_US}}, open(a.json, "w"), indent=1)
+                   "assumptions": {"link_GBps": LINK_GBPS, "efficiency": EFF, "window_exchange_us": T_WINDOW_US,
+                                   "allreduce": "measured: the peer-board kernel on a board of one rank"}},
+                  open(a.json, "w"), indent=1)
 
 
 if __name__ == "__main__":
