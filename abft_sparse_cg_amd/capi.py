@@ -89,6 +89,7 @@ SIGNATURES = {
     "abft_hip_peer_board_detach": (C.c_int, [vp]),
     "abft_hip_allreduce_pair_peers": (C.c_int, [vp, vp]),
     "abft_hip_peer_board_failed": (C.c_int, [vp]),
+    "abft_hip_peer_board_fuse": (C.c_int, [vp, C.c_int]),
     "abft_hip_peer_exchange_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
     "abft_hip_peer_exchange_attach": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, vp,
                                                 C.c_int, C.c_double]),

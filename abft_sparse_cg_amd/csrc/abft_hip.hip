@@ -90,6 +90,7 @@ struct abft_hip_ctx {
     unsigned long long *counter = nullptr;  // device: sequence number of the last all-reduce
     int rank = 0, size = 0;
     unsigned long long timeout_ticks = 0;
+    bool fuse = false;  // device-scalar reductions end with the all-reduce (abft_hip_peer_board_fuse)
   } peers;
   // window exchange over shared host memory (abft_hip_peer_exchange_attach)
   struct {
@@ -1103,8 +1104,20 @@ extern "C" int abft_hip_vector_length(abft_hip_vector *vec) { return vec ? vec->
 
 // --------------------------------------------------------------- CG kernels --
 
+static PeerArgs peer_args(const abft_hip_ctx *ctx) {
+  PeerArgs P{};
+  P.board = ctx->peers.dev;
+  P.counter = ctx->peers.counter;
+  P.fail = reinterpret_cast<uint32_t *>(ctx->peers.dev + 2 * ABFT_PEER_MAX_RANKS);
+  P.rank = ctx->peers.rank;
+  P.size = ctx->peers.size;
+  P.timeout_ticks = ctx->peers.timeout_ticks;
+  return P;
+}
+
 static ReduceOut reduce_out(abft_hip_ctx *ctx, double *dev_out, bool to_host) {
-  ReduceOut o;
+  ReduceOut o{};
+  if (dev_out && !to_host && ctx->peers.fuse) o.peers = peer_args(ctx);
   o.partials = ctx->partials;
   o.ticket = ctx->ticket;
   o.dev_out = dev_out;
@@ -1329,9 +1342,18 @@ extern "C" int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair
   if (int rc = bind(ctx, true)) return rc;
   if (!dev_pair) return set_err(ABFT_ERR_INVALID, "null argument");
   if (!ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
-  uint32_t *fail = reinterpret_cast<uint32_t *>(ctx->peers.dev + 2 * ABFT_PEER_MAX_RANKS);
-  HIPCHK(launch_peer_allreduce(dev_pair, ctx->peers.dev, ctx->peers.counter, fail, ctx->peers.rank, ctx->peers.size,
-                               ctx->peers.timeout_ticks, ctx->stream));
+  HIPCHK(launch_peer_allreduce(dev_pair, peer_args(ctx), ctx->stream));
+  return ABFT_OK;
+}
+
+// on: from now on every device-scalar reduction of this context (abft_hip_dot_dev, abft_hip_calc_xr_dev,
+// abft_hip_calc_xr_ratio_dev, the product of abft_hip_spmv_dot_*_dev) delivers {sum, events} already summed
+// over the ranks of the board -- the block that finishes the shard's sum does the all-reduce in its tail,
+// no kernel of its own.  Every rank must switch at the same point of its call sequence.
+extern "C" int abft_hip_peer_board_fuse(abft_hip_ctx *ctx, int on) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (on && !ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
+  ctx->peers.fuse = on != 0;
   return ABFT_OK;
 }
 
@@ -1508,6 +1530,7 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
     fuse.ev_count = ctx->ring.count;
     fuse.seq = dev_pair ? 0 : ++ctx->seq;
     fuse.x_off = dev_pair ? (uint32_t)vec_offset : 0u;
+    if (dev_pair && ctx->peers.fuse) fuse.peers = peer_args(ctx);
   }
   uint32_t nparts = mat->fmt == ABFT_FMT_CSR ? mat->csr.nblk : mat->coo.nblk;
   FixArgs fix{};
@@ -1543,7 +1566,7 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
     ReduceOut big{};  // same outputs as the one-block fold, reached through the reduction protocol
     big.partials = ctx->partials; big.ticket = ctx->ticket; big.dev_out = fuse.dev_out; big.host = fuse.host;
-    big.ev_count = fuse.ev_count; big.seq = fuse.seq;
+    big.ev_count = fuse.ev_count; big.seq = fuse.seq; big.peers = fuse.peers;
     HIPCHK(launch_fuse_finalize(fuse, nparts, big, fix.on ? &fix : nullptr, ctx->stream));
   }
   if (to_host && do_fuse) {

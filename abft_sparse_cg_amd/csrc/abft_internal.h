@@ -175,6 +175,23 @@ struct HostSlot {
   uint32_t seq;
 };
 
+// peer board (all-reduce of a pair across the processes of one node, see kernels.hip):
+// [2 rows][ABFT_PEER_MAX_RANKS] slots, then one failure flag per rank
+#define ABFT_PEER_MAX_RANKS 64
+struct PeerSlot {
+  unsigned long long v0, v1, seq, pad;
+};
+#define ABFT_PEER_BOARD_BYTES (2 * ABFT_PEER_MAX_RANKS * sizeof(PeerSlot) + ABFT_PEER_MAX_RANKS * sizeof(uint32_t))
+// ... as the tail of a reduction: the block that finishes the shard's sum also takes it over the
+// board (size == 0: no)
+struct PeerArgs {
+  PeerSlot *board;
+  unsigned long long *counter;
+  uint32_t *fail;
+  int rank, size;
+  unsigned long long timeout_ticks;
+};
+
 // Where a reduction delivers its result.  Every block writes one partial, takes
 // a ticket (agent-scope release before, acquire after for the last arriver), and
 // the block that draws the last ticket adds the partials in a fixed order, so the
@@ -186,6 +203,7 @@ struct ReduceOut {
   HostSlot *host;            // optional: device alias of the pinned slot
   const uint32_t *ev_count;  // the context's device event counter
   uint32_t seq;              // value to publish in host->seq
+  PeerArgs peers;            // dev_out form: {sum, events} summed over the ranks of the board before it is stored
 };
 
 // Cross-call fusion: an SpMV on a square matrix also forms
@@ -201,6 +219,7 @@ struct FuseOut {
   const uint32_t *ev_count;
   uint32_t seq;
   uint32_t x_off;    // the product uses vec[x_off + row] (a shard's slot in the gathered vector)
+  PeerArgs peers;    // as in ReduceOut
 };
 
 // Which row blocks (tiles) of a streaming-layout CSR matrix one launch covers:
@@ -268,13 +287,6 @@ hipError_t launch_calc_px(double *p, const double *r, double *x, double beta, co
 hipError_t launch_axpy(double *x, const double *p, double alpha, const double *alpha_ptr, int n, hipStream_t s);
 hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq, hipStream_t s);
 
-// peer board (all-reduce of a pair across the processes of one node, see kernels.hip):
-// [2 rows][ABFT_PEER_MAX_RANKS] slots, then one failure flag per rank
-#define ABFT_PEER_MAX_RANKS 64
-struct PeerSlot {
-  unsigned long long v0, v1, seq, pad;
-};
-#define ABFT_PEER_BOARD_BYTES (2 * ABFT_PEER_MAX_RANKS * sizeof(PeerSlot) + ABFT_PEER_MAX_RANKS * sizeof(uint32_t))
 // window exchange over shared host memory (see kernels.hip, peer_exchange_kernel): a 4 KB header
 // -- ready[rank], done[rank] sequence numbers, fail[rank] -- then per rank two outboxes (parity)
 #define ABFT_PEER_MAX_PIECES 63
@@ -294,8 +306,7 @@ struct PeerExchange {  // lives in device memory
   PeerPiece out[ABFT_PEER_MAX_PIECES], in[ABFT_PEER_MAX_PIECES];
 };
 hipError_t launch_peer_exchange(const PeerExchange *X, double *full, hipStream_t s);
-hipError_t launch_peer_allreduce(double *pair, PeerSlot *board, unsigned long long *counter, uint32_t *fail, int rank,
-                                 int size, unsigned long long timeout_ticks, hipStream_t s);
+hipError_t launch_peer_allreduce(double *pair, const PeerArgs &P, hipStream_t s);
 hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s);
 hipError_t launch_stream_copy(double *dst, const double *src, size_t n, hipStream_t s);
 hipError_t launch_stream_read(const double *src, size_t n, double *sink, hipStream_t s);

@@ -216,6 +216,65 @@ __device__ void coo_fixup_body(const FixArgs &fx);
 
 // ------------------------------------------------------ fused dot epilogue --
 
+// All-reduce of {v0, v1} (held by thread 0) across the ranks of a peer board, by every thread
+// of the calling block: see peer_allreduce_kernel below for the protocol.  Thread 0 returns
+// the sums in rank order; a rank that gives up waiting gets NaN and raises its flag.
+__device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, const PeerArgs &P) {
+  __shared__ double s_pv[2][ABFT_PEER_MAX_RANKS];
+  __shared__ unsigned long long s_pseq;
+  __shared__ uint32_t s_pbad;
+  const uint32_t t = threadIdx.x;
+  if (t == 0) {
+    const unsigned long long seq = *P.counter + 1ull;  // written by the previous all-reduce on this stream
+    PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
+    __hip_atomic_store(&mine->v0, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mine->v1, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&mine->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    s_pseq = seq;
+    s_pbad = 0u;
+  }
+  __syncthreads();
+  const unsigned long long seq = s_pseq;
+  if (t < (uint32_t)P.size) {
+    const PeerSlot *slot = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + t;
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+      if ((unsigned long long)wall_clock64() - t0 > P.timeout_ticks) {
+        ok = false;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    double a = 0.0, b = 0.0;
+    if (ok) {
+      a = __longlong_as_double((long long)__hip_atomic_load(&slot->v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+      b = __longlong_as_double((long long)__hip_atomic_load(&slot->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    } else {
+      atomicOr(&s_pbad, 1u);
+    }
+    s_pv[0][t] = a;
+    s_pv[1][t] = b;
+  }
+  __syncthreads();
+  if (t == 0) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < P.size; r++) {
+      s0 += s_pv[0][r];
+      s1 += s_pv[1][r];
+    }
+    if (s_pbad) {
+      s0 = __longlong_as_double(0x7ff8000000000000ll);
+      __hip_atomic_store(P.fail + P.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    v0 = s0;
+    v1 = s1;
+    *P.counter = seq;
+  }
+}
+
+
 // Tail of an SpMV launched with a FuseOut: `dsum` is this thread's share of
 // sum vec[row]*result[row].  The block leaves one partial with a plain store
 // and exits -- nothing here waits on memory.  (An in-kernel ticket protocol
@@ -248,13 +307,18 @@ __global__ __launch_bounds__(1024) void fuse_finalize_kernel(FuseOut f, uint32_t
   acc = wave_sum(acc);
   if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = acc;
   __syncthreads();
+  double tot = 0.0, evs = 0.0;
+  uint32_t nev = 0u;
   if (threadIdx.x == 0) {
-    double tot = 0.0;
     for (int k = 0; k < 16; k++) tot += s_w[k];
-    const uint32_t nev = *f.ev_count;
+    nev = *f.ev_count;
+    evs = (double)nev;
+  }
+  if (f.peers.size) peer_allreduce_block(tot, evs, f.peers);  // (uniform: a kernel argument)
+  if (threadIdx.x == 0) {
     if (f.dev_out) {
       f.dev_out[0] = tot;
-      f.dev_out[1] = (double)nev;
+      f.dev_out[1] = evs;
     }
     if (f.host) {
       __hip_atomic_store(&f.host->value, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1552,11 +1616,17 @@ __device__ __forceinline__ void reduce_finish(double block_value, const ReduceOu
   for (uint32_t i = threadIdx.x; i < gridDim.x; i += ABFT_BLOCK)  // fixed order
     acc += __hip_atomic_load(o.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   acc = block_sum(acc, s_w);
+  uint32_t nev = 0u;
+  double evs = 0.0;
   if (threadIdx.x == 0) {
-    const uint32_t nev = __hip_atomic_load(o.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (o.dev_out) {  // shard-local form: {partial sum, queued events} for one all-reduce
+    nev = __hip_atomic_load(o.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    evs = (double)nev;
+  }
+  if (o.peers.size) peer_allreduce_block(acc, evs, o.peers);  // the whole (last) block; uniform: a kernel argument
+  if (threadIdx.x == 0) {
+    if (o.dev_out) {  // {sum, queued events} of this shard -- or of all ranks, when the board is in the tail
       o.dev_out[0] = acc;
-      o.dev_out[1] = (double)nev;
+      o.dev_out[1] = evs;
     }
     __hip_atomic_store(o.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     if (o.host) {
@@ -1862,65 +1932,21 @@ hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq,
 // k + 1.  One kernel node: capturable, nothing to set up at first use, and the latency is two
 // PCIe crossings instead of a collective's launch and protocol.  Every wait is bounded; a
 // rank that gives up leaves NaN and raises its flag on the board.
-__global__ __launch_bounds__(64) void peer_allreduce_kernel(double *pair, PeerSlot *board,
-                                                            unsigned long long *counter, uint32_t *fail, int rank,
-                                                            int size, unsigned long long timeout_ticks) {
-  __shared__ double s_v[2][ABFT_PEER_MAX_RANKS];
-  __shared__ uint32_t s_bad;
-  const int lane = (int)threadIdx.x;
-  const unsigned long long seq = *counter + 1ull;  // written by the previous launch on this stream
-  PeerSlot *row = board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS;
-  if (lane == 0) {
-    s_bad = 0u;
-    __hip_atomic_store(&row[rank].v0, (unsigned long long)__double_as_longlong(pair[0]), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&row[rank].v1, (unsigned long long)__double_as_longlong(pair[1]), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&row[rank].seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+__global__ __launch_bounds__(64) void peer_allreduce_kernel(double *pair, PeerArgs P) {
+  double v0 = 0.0, v1 = 0.0;
+  if (threadIdx.x == 0) {
+    v0 = pair[0];
+    v1 = pair[1];
   }
-  __syncthreads();
-  double a = 0.0, b = 0.0;
-  if (lane < size) {
-    const unsigned long long t0 = (unsigned long long)wall_clock64();
-    bool ok = true;
-    while (__hip_atomic_load(&row[lane].seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) {
-        ok = false;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if (ok) {
-      a = __longlong_as_double((long long)__hip_atomic_load(&row[lane].v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-      b = __longlong_as_double((long long)__hip_atomic_load(&row[lane].v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-    } else {
-      atomicOr(&s_bad, 1u);
-    }
-    s_v[0][lane] = a;
-    s_v[1][lane] = b;
-  }
-  __syncthreads();
-  if (lane == 0) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int r = 0; r < size; r++) {
-      s0 += s_v[0][r];
-      s1 += s_v[1][r];
-    }
-    if (s_bad) {
-      s0 = __longlong_as_double(0x7ff8000000000000ll);
-      __hip_atomic_store(fail + rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    pair[0] = s0;
-    pair[1] = s1;
-    *counter = seq;
+  peer_allreduce_block(v0, v1, P);
+  if (threadIdx.x == 0) {
+    pair[0] = v0;
+    pair[1] = v1;
   }
 }
 
-hipError_t launch_peer_allreduce(double *pair, PeerSlot *board, unsigned long long *counter, uint32_t *fail, int rank,
-                                 int size, unsigned long long timeout_ticks, hipStream_t s) {
-  hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(64), 0, s, pair, board, counter, fail, rank, size,
-                     timeout_ticks);
+hipError_t launch_peer_allreduce(double *pair, const PeerArgs &P, hipStream_t s) {
+  hipLaunchKernelGGL(peer_allreduce_kernel, dim3(1), dim3(64), 0, s, pair, P);
   return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
     r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
-    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false),
+    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false), fuse_allreduce_(false),
     one_node_(false), xchg_map_(NULL), xchg_bytes_(0), peer_xchg_ok_(false)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
@@ -252,6 +252,8 @@ void HIPContextBase::check_peer_board()
 
 void HIPContextBase::device_allreduce(double *dev_pair)
 {
+  if (fuse_allreduce_)
+    return;  // the reduction that produced the pair has summed it over the ranks already
   if (peers_ok_)
     check(abft_hip_allreduce_pair_peers(ctx_, dev_pair), "abft_hip_allreduce_pair_peers");
   else if (comm_->device_collectives())
@@ -837,6 +839,14 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
   if (comm_)
   {
     device_allreduce(fixed_scal_dev_);
+    // from here on the two all-reduces of an iteration ride in the tails of the kernels that
+    // finish the shard's sums (the fold of p.w, calc_xr's last block): two launches less per iteration
+    const char *env = getenv("ABFT_COMM_FUSE_ALLREDUCE");
+    if (peers_ok_ && !(env && !strcmp(env, "0")))
+    {
+      check(abft_hip_peer_board_fuse(ctx_, 1), "abft_hip_peer_board_fuse");
+      fuse_allreduce_ = true;
+    }
   }
   // Replay: the iteration is captured once per parity (the rr pairs swap roles) and launched as
   // a graph -- kernels, the exchange and both all-reduces are graph nodes.  Not with host-staged
@@ -929,6 +939,11 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     check(abft_hip_profile_enable(ctx_, 0), "abft_hip_profile_enable");
     printf("bench_spmv: rank %d spmvs %d brackets %ld total_us %.3f local_rows %d local_nnz %u\n", ext_rank(), extra,
            launches, ms * 1e3, comm_ ? n_loc_ : A->N, A->nnz_local);
+  }
+  if (fuse_allreduce_)
+  {
+    check(abft_hip_peer_board_fuse(ctx_, 0), "abft_hip_peer_board_fuse");
+    fuse_allreduce_ = false;
   }
   if (comm_ || v[1] > 0.0)
     report_events(true);  // collective across ranks: every rank calls it

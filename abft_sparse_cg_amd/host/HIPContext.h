@@ -128,6 +128,7 @@ private:
   void *board_map_;              // shared mapping behind the peer board (NULL: not in use)
   size_t board_bytes_;
   bool peers_ok_;                // every rank attached the board and it summed correctly
+  bool fuse_allreduce_;          // run_fixed: the all-reduces run in the tails of the reductions themselves
   bool one_node_;                // every rank runs on this host
   void *xchg_map_;               // shared mapping behind the window exchange (NULL: not in use)
   size_t xchg_bytes_;

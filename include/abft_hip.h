@@ -233,6 +233,11 @@ int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, in
                                double timeout_seconds);
 int abft_hip_peer_board_detach(abft_hip_ctx *ctx);
 int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair);
+/* on != 0: every device-scalar reduction of the context from now on (abft_hip_dot_dev,
+ * abft_hip_calc_xr_dev, abft_hip_calc_xr_ratio_dev, the product of abft_hip_spmv_dot_*_dev)
+ * delivers its pair already summed over the ranks: the all-reduce runs in the tail of the
+ * block that finishes the shard's sum, no kernel of its own.  All ranks switch together. */
+int abft_hip_peer_board_fuse(abft_hip_ctx *ctx, int on);
 int abft_hip_peer_board_failed(abft_hip_ctx *ctx);
 
 /* The windows of the gathered vector that a rank's peers read (the halo of a banded matrix)

@@ -310,6 +310,21 @@ def test_scalar_allreduces_over_the_peer_board_equal_the_collective_layer(fmt):
     assert strip(board.stdout) == strip(layer.stdout) and "corrected bit" in board.stdout
 
 
+def test_bench_loop_fused_and_unfused_allreduces_same_bits():
+    """--bench at three ranks on the one GPU: everything in the replayed graph (peer board + outboxes);
+    the all-reduces in the tails of the reductions (default) or as kernels of their own, same rr bits"""
+    args = ["-t", "hip", "-m", "secded", "-s", "laplace5:150,150", "--bench", "4,31", "-q"]
+    fused = run_ranks(3, args, ("--one-gpu",))
+    apart = run_ranks(3, args, ("--one-gpu",), env={"ABFT_COMM_FUSE_ALLREDUCE": "0"})
+    eager = run_ranks(3, args, ("--one-gpu",), env={"ABFT_CG_GRAPH": "0"})
+    one = run("csr", args)
+    for p in (fused, apart, eager, one):
+        assert p.returncode == 0, p.stderr[-800:]
+    a, b, c, d = (bench_line(p.stdout) for p in (fused, apart, eager, one))
+    assert a[0] == b[0] == c[0] == 3 and a[4] == b[4] == c[4]
+    assert abs(a[4] - d[4]) <= 1e-10 * d[4]
+
+
 def test_run_tests_script_passes_column_partitioned_coo():
     launcher = "%s 2 --one-gpu -- %s" % (os.path.join(HOST, "mgpu-run"), exe("coo"))
     p = subprocess.run([os.path.join(HOST, "run_tests"), launcher], capture_output=True, text=True, timeout=1500)

@@ -189,3 +189,37 @@ def test_exchange_gives_up_loudly_and_refuses_bad_windows(two_ranks_with_outboxe
     got = c.download(v)
     assert math.isnan(got[32]) and L.abft_hip_peer_exchange_failed(c.h) == 1
     capi.check(L.abft_hip_peer_exchange_detach(c.h))
+
+
+def test_all_reduce_in_the_tail_of_the_reductions(pair_of_contexts):
+    """abft_hip_peer_board_fuse: dot_dev / calc_xr_dev / the product of spmv_dot_dev deliver {sum, events}
+    already summed over the ranks -- same bits as the reduction followed by the all-reduce kernel"""
+    L, capi, ctxs, pairs, addr, nbytes = pair_of_contexts
+    for r, c in enumerate(ctxs):
+        capi.check(L.abft_hip_peer_board_attach(c.h, addr[r], nbytes, r, 2, 20.0))
+    rng = np.random.default_rng(3)
+    n = [70001, 1234]  # several blocks on one rank, one on the other
+    vecs = []
+    for c, m in zip(ctxs, n):
+        a, b = c.create_vector(m), c.create_vector(m)
+        c.upload(a, rng.standard_normal(m))
+        c.upload(b, rng.standard_normal(m))
+        vecs.append((a, b))
+
+    def both(fused):
+        for c in ctxs:
+            capi.check(L.abft_hip_peer_board_fuse(c.h, 1 if fused else 0))
+        for c, p, (a, b) in zip(ctxs, pairs, vecs):
+            capi.check(L.abft_hip_dot_dev(c.h, a.h, b.h, p.device_ptr))
+            if not fused:
+                capi.check(L.abft_hip_allreduce_pair_peers(c.h, p.device_ptr))
+        return [read_pair(L, capi, c, p) for c, p in zip(ctxs, pairs)]
+
+    plain = both(False)
+    fused = both(True)
+    again = both(False)
+    assert plain[0] == plain[1] and fused == plain and again == plain
+    for c in ctxs:
+        capi.check(L.abft_hip_peer_board_fuse(c.h, 0))
+    assert L.abft_hip_peer_board_fuse(ctxs[0].h, 1) == 0 and L.abft_hip_peer_board_detach(ctxs[0].h) == 0
+    assert L.abft_hip_peer_board_fuse(ctxs[0].h, 1) != 0  # not attached any more

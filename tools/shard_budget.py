@@ -11,9 +11,10 @@ host/partition.cpp), and times the iteration's kernels through the C ABI with th
 resident on the device and the iteration replayed as a hipGraph (what host/cg-csr --bench
 runs, minus the collectives):  spmv+dot, calc_xr (r half), calc_p (+x half).
 Measured besides: the host cost of one graph launch.  For G > 1 the replayed iteration also holds
-the two scalar all-reduces as the multi-process host enqueues them -- the peer-board kernel
-(abft_hip_allreduce_pair_peers) on a board of ONE rank: two PCIe crossings and a launch each,
-i.e. what they cost when all peers arrive together; the skew between real ranks is not in it.
+the two scalar all-reduces as the multi-process host runs them -- over the peer board, in the tails
+of the kernels that finish the shard's sums (abft_hip_peer_board_fuse), on a board of ONE rank: two
+PCIe crossings each, i.e. what they cost when all peers arrive together; the skew between real
+ranks is not in it.
 
 Projection per iteration at G ranks:
     T(G) = max_k kernels(G, k)  [incl. the two board all-reduces]  + T_exchange(G)
@@ -80,15 +81,12 @@ def time_shard(mode, pin, lrows, vals, n_loc, n_pad, slot, k, iters=60, allreduc
     if allreduce:  # a board of one rank: the all-reduce kernel's own cost
         board = mmap.mmap(-1, L.abft_hip_peer_board_bytes())
         capi.check(L.abft_hip_peer_board_attach(h, C.addressof(C.c_char.from_buffer(board)), len(board), 0, 1, 5.0))
+        capi.check(L.abft_hip_peer_board_fuse(h, 1))  # in the tails of the reductions, as host/HIPContext.cpp runs them
 
     def it(parity):
         cur, nxt, pw = base + 16 * parity, base + 16 * (1 - parity), base + 32
         capi.check(L.abft_hip_spmv_dot_dev(h, A.h, pfull.h, w.h, k * slot, pw))
-        if allreduce:
-            capi.check(L.abft_hip_allreduce_pair_peers(h, pw))
         capi.check(L.abft_hip_calc_xr_ratio_dev(h, x.h, r.h, p.h, w.h, cur, pw, nxt))
-        if allreduce:
-            capi.check(L.abft_hip_allreduce_pair_peers(h, nxt))
         capi.check(L.abft_hip_calc_p_ratio_dev(h, p.h, r.h, nxt, cur))
     it(0); it(1)
     ctx.synchronize()
