@@ -1394,7 +1394,7 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
     const abft_peer_piece &p = k < nout ? out[k] : in[k - nout];
     // a window must lie inside its outbox (8-byte aligned) and name another rank
     if (p.peer < 0 || p.peer >= size || p.peer == rank || (p.box_offset & 7u) || p.box_offset > box ||
-        (size_t)p.count * sizeof(double) > box - p.box_offset)
+        ((size_t)p.count + 1u) * sizeof(double) > box - p.box_offset)  // (+ the check word behind it)
       return set_err(ABFT_ERR_RANGE, "peer exchange: window %d (peer %d, %u doubles at byte %llu of an outbox of %zu) "
                      "does not fit", k, p.peer, p.count, (unsigned long long)p.box_offset, box);
     PeerPiece &d = k < nout ? X.out[k] : X.in[k - nout];

@@ -219,6 +219,11 @@ __device__ void coo_fixup_body(const FixArgs &fx);
 // All-reduce of {v0, v1} (held by thread 0) across the ranks of a peer board, by every thread
 // of the calling block: see peer_allreduce_kernel below for the protocol.  Thread 0 returns
 // the sums in rank order; a rank that gives up waiting gets NaN and raises its flag.
+__device__ __forceinline__ unsigned long long peer_check_word(unsigned long long seq, double v0, double v1) {
+  return (seq * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)__double_as_longlong(v0) ^
+         ((unsigned long long)__double_as_longlong(v1) << 1 | (unsigned long long)__double_as_longlong(v1) >> 63);
+}
+
 __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, const PeerArgs &P) {
   __shared__ double s_pv[2][ABFT_PEER_MAX_RANKS];
   __shared__ unsigned long long s_pseq;
@@ -229,6 +234,9 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
     PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
     __hip_atomic_store(&mine->v0, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&mine->v1, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (a word that ties the three together: a reader that sees the new sequence number next to an
+    // old value -- stores overtaking each other on the way, which the release below forbids -- keeps polling)
+    __hip_atomic_store(&mine->pad, peer_check_word(seq, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(&mine->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     s_pseq = seq;
@@ -239,19 +247,22 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
   if (t < (uint32_t)P.size) {
     const PeerSlot *slot = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + t;
     const unsigned long long t0 = (unsigned long long)wall_clock64();
-    bool ok = true;
-    while (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-      if ((unsigned long long)wall_clock64() - t0 > P.timeout_ticks) {
-        ok = false;
-        break;
+    bool ok = false;
+    double a = 0.0, b = 0.0;
+    for (;;) {
+      if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) {
+        a = __longlong_as_double((long long)__hip_atomic_load(&slot->v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        b = __longlong_as_double((long long)__hip_atomic_load(&slot->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        if (__hip_atomic_load(&slot->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == peer_check_word(seq, a, b)) {
+          ok = true;
+          break;
+        }
       }
+      if ((unsigned long long)wall_clock64() - t0 > P.timeout_ticks) break;
       __builtin_amdgcn_s_sleep(8);
     }
-    double a = 0.0, b = 0.0;
-    if (ok) {
-      a = __longlong_as_double((long long)__hip_atomic_load(&slot->v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-      b = __longlong_as_double((long long)__hip_atomic_load(&slot->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-    } else {
+    if (!ok) {
+      a = b = 0.0;
       atomicOr(&s_pbad, 1u);
     }
     s_pv[0][t] = a;
@@ -1971,7 +1982,8 @@ __device__ __forceinline__ bool peer_wait_ge(const unsigned long long *word, uns
 }
 
 __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange *Xp, double *__restrict__ full) {
-  __shared__ uint32_t s_bad;
+  __shared__ uint32_t s_bad, s_retry;
+  __shared__ uint32_t s_x[2];  // xor of the 64-bit words of the window in hand, as two halves
   const PeerExchange &X = *Xp;
   const uint32_t t = threadIdx.x;
   const unsigned long long seq = *X.counter + 1ull;
@@ -1990,27 +2002,65 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
     const PeerPiece pc = X.out[k];
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(mybox + pc.box_off);
     const double *src = full + pc.vec_off;
-    for (uint32_t i = t; i < pc.count; i += 1024u)
-      __hip_atomic_store(dst + i, (unsigned long long)__double_as_longlong(src[i]), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t < 2u) s_x[t] = 0u;
+    __syncthreads();
+    unsigned long long x = 0ull;
+    for (uint32_t i = t; i < pc.count; i += 1024u) {
+      const unsigned long long w = (unsigned long long)__double_as_longlong(src[i]);
+      x ^= w;
+      __hip_atomic_store(dst + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    atomicXor(&s_x[0], (uint32_t)x);
+    atomicXor(&s_x[1], (uint32_t)(x >> 32));
+    __syncthreads();
+    // behind the window: a word that ties its contents to this exchange (see the reader)
+    if (t == 0)
+      __hip_atomic_store(dst + pc.count, ((unsigned long long)s_x[1] << 32 | s_x[0]) ^ (seq * 0x9E3779B97F4A7C15ull),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (t == 0) __hip_atomic_store(ready + X.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   if (t < (uint32_t)X.nin && !peer_wait_ge(ready + X.in[t].peer, seq, X.timeout_ticks)) atomicOr(&s_bad, 1u);
   __syncthreads();
-  const bool bad = s_bad != 0u;
-  for (int k = 0; k < X.nin && !bad; k++) {
+  for (int k = 0; k < X.nin && !s_bad; k++) {
     const PeerPiece pc = X.in[k];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
         X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)pc.peer * 2u + q) * X.box_bytes + pc.box_off);
     double *dst = full + pc.vec_off;
-    for (uint32_t i = t; i < pc.count; i += 1024u)
-      dst[i] = __longlong_as_double((long long)__hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    // The release / acquire pair above already orders the sender's stores before these loads; the
+    // check word makes a window that is not (yet) what its sender wrote for THIS exchange a re-read
+    // instead of a silently stale halo, whatever reorders stores between two devices and host memory.
+    const unsigned long long t0 = (unsigned long long)wall_clock64();
+    for (;;) {
+      if (t < 2u) s_x[t] = 0u;
+      if (t == 0) s_retry = 0u;
+      __syncthreads();
+      unsigned long long x = 0ull;
+      for (uint32_t i = t; i < pc.count; i += 1024u) {
+        const unsigned long long w = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        x ^= w;
+        dst[i] = __longlong_as_double((long long)w);
+      }
+      atomicXor(&s_x[0], (uint32_t)x);
+      atomicXor(&s_x[1], (uint32_t)(x >> 32));
+      __syncthreads();
+      if (t == 0) {
+        const unsigned long long want = __hip_atomic_load(src + pc.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((((unsigned long long)s_x[1] << 32 | s_x[0]) ^ (seq * 0x9E3779B97F4A7C15ull)) != want) {
+          if ((unsigned long long)wall_clock64() - t0 > X.timeout_ticks) s_bad = 1u;
+          else s_retry = 1u;
+        }
+      }
+      __syncthreads();
+      if (!s_retry) break;
+      __builtin_amdgcn_s_sleep(16);
+    }
   }
   __syncthreads();
   if (t == 0) {
-    if (bad) {
+    if (s_bad) {
       if (X.nin > 0) full[X.in[0].vec_off] = __longlong_as_double(0x7ff8000000000000ll);
       __hip_atomic_store(fail + X.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -177,7 +177,7 @@ void HIPContextBase::setup_peer_exchange()
       pc.box_offset = off;
       if (g == me) { pc.peer = q; out.push_back(pc); }
       if (q == me) { pc.peer = g; in.push_back(pc); }
-      off += ((size_t)pc.count * sizeof(double) + 255) & ~(size_t)255;
+      off += (((size_t)pc.count + 1) * sizeof(double) + 255) & ~(size_t)255;  // (+ the library's check word)
     }
     box = std::max(box, off);
   }

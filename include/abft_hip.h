@@ -246,8 +246,8 @@ int abft_hip_peer_board_failed(abft_hip_ctx *ctx);
  * for banded matrices).  `shared`: a page-aligned, zero-filled region of at least
  * abft_hip_peer_exchange_bytes(size, outbox_bytes) mapped by every process; every rank lays
  * the windows it sends out in its outbox (`box_offset`, 8-byte aligned, the same
- * outbox_bytes on every rank) and lists the windows it receives with the offsets their
- * senders chose.  `vector_offset` / `count` are in doubles from the start of the gathered
+ * outbox_bytes on every rank; behind each window 8 more bytes belong to the library: a
+ * check word) and lists the windows it receives with the offsets their senders chose.  `vector_offset` / `count` are in doubles from the start of the gathered
  * vector passed to abft_hip_peer_exchange.  Every rank must enqueue the same sequence of
  * exchanges.  Give-up after `timeout_seconds` (<= 0: 120): NaN in the first received window
  * and abft_hip_peer_exchange_failed() = 1. */

@@ -178,7 +178,7 @@ def test_exchange_gives_up_loudly_and_refuses_bad_windows(two_ranks_with_outboxe
     one = pieces([(1, 0, 8, 0)])
     assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(0, 0, 8, 0)]), 1, one, 1, 1.0) != 0  # to itself
     assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, 8, 4)]), 1, one, 1, 1.0) != 0  # unaligned
-    assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, box // 8 + 1, 0)]), 1, one, 1, 1.0) != 0
+    assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, box // 8, 0)]), 1, one, 1, 1.0) != 0  # no room for the check word
     assert L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes - 4096, 0, 2, box, one, 1, one, 1, 1.0) != 0
     capi.check(L.abft_hip_peer_exchange_attach(c.h, addr[0], nbytes, 0, 2, box, pieces([(1, 0, 8, 0)]), 1,
                                                pieces([(1, 32, 8, 0)]), 1, 0.5))
