@@ -361,7 +361,9 @@ def main():
                     "config": {"workload": "cg-%s -t hip -m %s, synthetic %s" % (args.fmt, args.mode, args.spec),
                                "N": hl["N"], "nnz": hl["nnz"], "format": args.fmt, "mode": args.mode,
                                "parallelism": "%d ranks (one process per GPU, C++ host over RCCL): output blocks cut by "
-                                              "non-zeros, exchange of the search vector + 2 all-reduces per iteration, "
+                                              "non-zeros, exchange of the search vector (all-gather: RCCL; halo windows: "
+                                              "shared host memory) + 2 all-reduces per iteration (peer board in shared "
+                                              "host memory, RCCL if that fails its start-up test), "
                                               "scalars device-resident, iteration %s" % (
                                                   args.gpus, "replayed as a hipGraph" if hl["graph_replay"] else
                                                   "enqueued eagerly (the graph replay failed on this stack)"),
