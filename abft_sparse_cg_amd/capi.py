@@ -95,6 +95,8 @@ SIGNATURES = {
                                                 C.c_int, C.c_double]),
     "abft_hip_peer_exchange_detach": (C.c_int, [vp]),
     "abft_hip_peer_exchange": (C.c_int, [vp, vp]),
+    "abft_hip_peer_exchange_begin": (C.c_int, [vp, vp, C.c_int]),
+    "abft_hip_peer_exchange_finish": (C.c_int, [vp]),
     "abft_hip_peer_exchange_failed": (C.c_int, [vp]),
     "abft_hip_matrix_panels": (C.c_int, [vp, i32p, i32p]),
     "abft_hip_spmv_dot_range_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]),

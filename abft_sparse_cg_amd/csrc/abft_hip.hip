@@ -99,6 +99,9 @@ struct abft_hip_ctx {
     unsigned long long *counter = nullptr;  // device: sequence number of the last exchange
     int rank = 0;
     size_t extent = 0;                      // doubles of the gathered vector the windows reach
+    hipStream_t side = nullptr;             // abft_hip_peer_exchange_begin(beside): the exchange runs here
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool pending = false;                   // a `beside` exchange that finish has not joined yet
   } xchg;
 };
 
@@ -1401,6 +1404,12 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
     extent = std::max(extent, (size_t)p.vector_offset + p.count);
     d.box_off = p.box_offset; d.vec_off = p.vector_offset; d.count = p.count; d.peer = p.peer; d.pad = 0;
   }
+  // a reader this rank receives nothing from must be asked before its outbox is reused (kernels.hip)
+  for (int k = 0; k < nout; k++) {
+    bool also_sender = false;
+    for (int j = 0; j < nin; j++) also_sender = also_sender || in[j].peer == out[k].peer;
+    X.out[k].pad = also_sender ? 0 : 1;
+  }
   if (hipHostRegister(shared, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
     return set_err(ABFT_ERR_HIP, "peer exchange: hipHostRegister of the shared mapping failed");
@@ -1425,6 +1434,9 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
   X.timeout_ticks = (unsigned long long)((timeout_seconds > 0 ? timeout_seconds : 120.0) * 1e3 * khz);
   HIPCHK(hipMemcpyAsync(dev, &X, sizeof(X), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));  // `X` is on the stack
+  HIPCHK(hipStreamCreateWithFlags(&ctx->xchg.side, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ctx->xchg.fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx->xchg.join, hipEventDisableTiming));
   ctx->xchg.host = shared;
   ctx->xchg.dev = dev;
   ctx->xchg.counter = counter;
@@ -1437,24 +1449,52 @@ extern "C" int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx) {
   if (!ctx || !ctx->xchg.host) return ABFT_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->xchg.side) (void)hipStreamSynchronize(ctx->xchg.side);
   (void)hipHostUnregister(ctx->xchg.host);
   (void)hipFree(ctx->xchg.dev);
   (void)hipFree(ctx->xchg.counter);
+  if (ctx->xchg.fork) (void)hipEventDestroy(ctx->xchg.fork);
+  if (ctx->xchg.join) (void)hipEventDestroy(ctx->xchg.join);
+  if (ctx->xchg.side) (void)hipStreamDestroy(ctx->xchg.side);
   (void)hipGetLastError();
   ctx->xchg = {};
   return ABFT_OK;
 }
 
-// the windows of `full` (a gathered vector of this context) exchanged with the peers, enqueue-only
-extern "C" int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full) {
+// the windows of `full` (a gathered vector of this context) exchanged with the peers, enqueue-only.
+// beside != 0: on a side stream that starts behind everything enqueued on the context's stream so
+// far; what the caller enqueues until abft_hip_peer_exchange_finish runs next to the exchange (the
+// rows of an SpMV that read no window).  Captured into a graph the two event hand-offs are edges.
+extern "C" int abft_hip_peer_exchange_begin(abft_hip_ctx *ctx, abft_hip_vector *full, int beside) {
   if (int rc = bind(ctx)) return rc;
   if (!full) return set_err(ABFT_ERR_INVALID, "null argument");
   if (!ctx->xchg.host) return set_err(ABFT_ERR_INVALID, "peer exchange: not attached");
+  if (ctx->xchg.pending) return set_err(ABFT_ERR_INVALID, "peer exchange: the previous one was not finished");
   if (full->ctx != ctx || (size_t)full->n < ctx->xchg.extent)
     return set_err(ABFT_ERR_RANGE, "peer exchange: the windows reach %zu doubles, the vector holds %d", ctx->xchg.extent,
                    full->n);
-  HIPCHK(launch_peer_exchange(ctx->xchg.dev, full->d, ctx->stream));
+  if (!beside) {
+    HIPCHK(launch_peer_exchange(ctx->xchg.dev, full->d, ctx->stream));
+    return ABFT_OK;
+  }
+  HIPCHK(hipEventRecord(ctx->xchg.fork, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->xchg.side, ctx->xchg.fork, 0));
+  HIPCHK(launch_peer_exchange(ctx->xchg.dev, full->d, ctx->xchg.side));
+  HIPCHK(hipEventRecord(ctx->xchg.join, ctx->xchg.side));
+  ctx->xchg.pending = true;
   return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_finish(abft_hip_ctx *ctx) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!ctx->xchg.pending) return ABFT_OK;
+  ctx->xchg.pending = false;
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->xchg.join, 0));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full) {
+  return abft_hip_peer_exchange_begin(ctx, full, 0);
 }
 
 extern "C" int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx) {

@@ -237,8 +237,10 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
     // (a word that ties the three together: a reader that sees the new sequence number next to an
     // old value -- stores overtaking each other on the way, which the release below forbids -- keeps polling)
     __hip_atomic_store(&mine->pad, peer_check_word(seq, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (no release fence: it would first write back every dirty line of this XCD's L2 -- the vector the
+    // reduction's kernel has just written; the stores above are write-through and have been waited for)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&mine->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&mine->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     s_pseq = seq;
     s_pbad = 0u;
   }
@@ -250,7 +252,7 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
     bool ok = false;
     double a = 0.0, b = 0.0;
     for (;;) {
-      if (__hip_atomic_load(&slot->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == seq) {
+      if (__hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) {
         a = __longlong_as_double((long long)__hip_atomic_load(&slot->v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         b = __longlong_as_double((long long)__hip_atomic_load(&slot->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         if (__hip_atomic_load(&slot->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == peer_check_word(seq, a, b)) {
@@ -259,7 +261,7 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
         }
       }
       if ((unsigned long long)wall_clock64() - t0 > P.timeout_ticks) break;
-      __builtin_amdgcn_s_sleep(8);
+      __builtin_amdgcn_s_sleep(4);
     }
     if (!ok) {
       a = b = 0.0;
@@ -1971,14 +1973,58 @@ hipError_t launch_peer_allreduce(double *pair, const PeerArgs &P, hipStream_t s)
 // sequence number; before a rank overwrites an outbox it waits until its readers have
 // finished with the exchange two back (`done`), so the protocol does not lean on whatever
 // else synchronises the ranks in between.  Capturable, bounded waits, NaN + flag on give-up.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// Accesses to the shared region that go to memory whatever the caches hold (sc0 sc1: system
+// coherence level), 16 bytes wide: the compiler has no 16-byte system-scope atomic, and 8-byte
+// ones cross the link one request per lane.  No fences anywhere in this kernel -- a system-scope
+// release writes back every dirty line of the XCD's L2 first (the vectors the iteration has just
+// written) -- the order comes from waiting for the stores (vmcnt) before the flag is stored.
+__device__ __forceinline__ void sys_store_b128(u64x2 *p, u64x2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void sys_store_b64(unsigned long long *p, unsigned long long v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void sys_load4_b128(const u64x2 *p0, const u64x2 *p1, const u64x2 *p2, const u64x2 *p3,
+                                               u64x2 &w0, u64x2 &w1, u64x2 &w2, u64x2 &w3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+__device__ __forceinline__ unsigned long long sys_load_b64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ bool peer_wait_ge(const unsigned long long *word, unsigned long long want,
                                              unsigned long long timeout_ticks) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
-  while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+  while (sys_load_b64(word) < want) {
     if ((unsigned long long)wall_clock64() - t0 > timeout_ticks) return false;
-    __builtin_amdgcn_s_sleep(8);
+    __builtin_amdgcn_s_sleep(4);
   }
   return true;
+}
+
+// xor of `x` over the block into s_x[0..1] (low, high half): inside each wave by lane exchange, then
+// one LDS atomic pair per wave (1024 threads on two LDS words took 3.5 us, measured)
+__device__ __forceinline__ void block_xor_into(uint32_t *s_x, unsigned long long x) {
+  uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    lo ^= (uint32_t)__shfl_xor((int)lo, m);
+    hi ^= (uint32_t)__shfl_xor((int)hi, m);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    atomicXor(&s_x[0], lo);
+    atomicXor(&s_x[1], hi);
+  }
 }
 
 __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange *Xp, double *__restrict__ full) {
@@ -1988,15 +2034,27 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
   const uint32_t t = threadIdx.x;
   const unsigned long long seq = *X.counter + 1ull;
   const unsigned long long q = seq & 1ull;
+  const unsigned long long salt = seq * 0x9E3779B97F4A7C15ull;
   unsigned long long *ready = reinterpret_cast<unsigned long long *>(X.shared);
   unsigned long long *done = ready + ABFT_PEER_MAX_RANKS;
   uint32_t *fail = reinterpret_cast<uint32_t *>(done + ABFT_PEER_MAX_RANKS);
   if (t == 0) s_bad = 0u;
+#ifdef ABFT_DBG_STAMPS  // timing build: wall-clock stamps (10 ns) of the phases, left in the header's spare half
+  unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define XSTAMP(k) st[k] = (unsigned long long)wall_clock64()
+#else
+#define XSTAMP(k)
+#endif
+  XSTAMP(0);
   __syncthreads();
-  // the readers of the outbox about to be overwritten are through with exchange seq - 2
-  if (t < (uint32_t)X.nout && seq > 2ull && !peer_wait_ge(done + X.out[t].peer, seq - 2ull, X.timeout_ticks))
+  // The readers of the outbox about to be overwritten are through with exchange seq - 2.  For a
+  // reader this rank also reads from that is known already: it published exchange seq - 1, which
+  // the last exchange waited for, and its stream runs its exchanges one after the other.  Only a
+  // reader this rank takes nothing from (pad != 0) is asked, which costs a trip across the link.
+  if (t < (uint32_t)X.nout && X.out[t].pad && seq > 2ull && !peer_wait_ge(done + X.out[t].peer, seq - 2ull, X.timeout_ticks))
     atomicOr(&s_bad, 1u);
   __syncthreads();
+  XSTAMP(1);
   unsigned char *mybox = X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)X.rank * 2u + q) * X.box_bytes;
   for (int k = 0; k < X.nout; k++) {
     const PeerPiece pc = X.out[k];
@@ -2005,53 +2063,84 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
     if (t < 2u) s_x[t] = 0u;
     __syncthreads();
     unsigned long long x = 0ull;
-    for (uint32_t i = t; i < pc.count; i += 1024u) {
+    const uint32_t npair = (pc.box_off & 15ull) == 0ull ? pc.count / 2u : 0u;
+    for (uint32_t j = t; j < npair; j += 1024u) {
+      const unsigned long long w0 = (unsigned long long)__double_as_longlong(src[2u * j]);
+      const unsigned long long w1 = (unsigned long long)__double_as_longlong(src[2u * j + 1u]);
+      x ^= w0 ^ w1;
+      sys_store_b128(reinterpret_cast<u64x2 *>(dst + 2u * j), u64x2{w0, w1});
+    }
+    for (uint32_t i = 2u * npair + t; i < pc.count; i += 1024u) {
       const unsigned long long w = (unsigned long long)__double_as_longlong(src[i]);
       x ^= w;
-      __hip_atomic_store(dst + i, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      sys_store_b64(dst + i, w);
     }
-    atomicXor(&s_x[0], (uint32_t)x);
-    atomicXor(&s_x[1], (uint32_t)(x >> 32));
+    block_xor_into(s_x, x);
     __syncthreads();
     // behind the window: a word that ties its contents to this exchange (see the reader)
-    if (t == 0)
-      __hip_atomic_store(dst + pc.count, ((unsigned long long)s_x[1] << 32 | s_x[0]) ^ (seq * 0x9E3779B97F4A7C15ull),
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (t == 0) sys_store_b64(dst + pc.count, ((unsigned long long)s_x[1] << 32 | s_x[0]) ^ salt);
     __syncthreads();
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  XSTAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores have been taken
   __syncthreads();
-  if (t == 0) __hip_atomic_store(ready + X.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  XSTAMP(3);
+  if (t == 0) sys_store_b64(ready + X.rank, seq);
   if (t < (uint32_t)X.nin && !peer_wait_ge(ready + X.in[t].peer, seq, X.timeout_ticks)) atomicOr(&s_bad, 1u);
   __syncthreads();
+  XSTAMP(4);
   for (int k = 0; k < X.nin && !s_bad; k++) {
     const PeerPiece pc = X.in[k];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
         X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)pc.peer * 2u + q) * X.box_bytes + pc.box_off);
     double *dst = full + pc.vec_off;
-    // The release / acquire pair above already orders the sender's stores before these loads; the
-    // check word makes a window that is not (yet) what its sender wrote for THIS exchange a re-read
-    // instead of a silently stale halo, whatever reorders stores between two devices and host memory.
+    // The sender stored the window, waited for those stores, then stored the sequence number this
+    // rank has now seen.  The check word makes a window that is not (yet) what its sender wrote for
+    // THIS exchange a re-read instead of a silently stale halo, whatever reorders stores on the way.
     const unsigned long long t0 = (unsigned long long)wall_clock64();
+    const uint32_t npair = (pc.box_off & 15ull) == 0ull ? pc.count / 2u : 0u;
     for (;;) {
       if (t < 2u) s_x[t] = 0u;
       if (t == 0) s_retry = 0u;
       __syncthreads();
-      unsigned long long x = 0ull;
-      for (uint32_t i = t; i < pc.count; i += 1024u) {
-        const unsigned long long w = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned long long x = 0ull, want = 0ull;
+      if (t == 1023u) want = sys_load_b64(src + pc.count);
+      for (uint32_t j0 = t; j0 < npair; j0 += 4096u) {  // four 16-byte loads across the link in flight per thread
+        const u64x2 *base = reinterpret_cast<const u64x2 *>(src);
+        const uint32_t j1 = j0 + 1024u, j2 = j0 + 2048u, j3 = j0 + 3072u;
+        u64x2 w0, w1, w2, w3;
+        sys_load4_b128(base + j0, base + (j1 < npair ? j1 : j0), base + (j2 < npair ? j2 : j0), base + (j3 < npair ? j3 : j0),
+                       w0, w1, w2, w3);
+        x ^= w0.x ^ w0.y;
+        dst[2u * j0] = __longlong_as_double((long long)w0.x);
+        dst[2u * j0 + 1u] = __longlong_as_double((long long)w0.y);
+        if (j1 < npair) {
+          x ^= w1.x ^ w1.y;
+          dst[2u * j1] = __longlong_as_double((long long)w1.x);
+          dst[2u * j1 + 1u] = __longlong_as_double((long long)w1.y);
+        }
+        if (j2 < npair) {
+          x ^= w2.x ^ w2.y;
+          dst[2u * j2] = __longlong_as_double((long long)w2.x);
+          dst[2u * j2 + 1u] = __longlong_as_double((long long)w2.y);
+        }
+        if (j3 < npair) {
+          x ^= w3.x ^ w3.y;
+          dst[2u * j3] = __longlong_as_double((long long)w3.x);
+          dst[2u * j3 + 1u] = __longlong_as_double((long long)w3.y);
+        }
+      }
+      for (uint32_t i = 2u * npair + t; i < pc.count; i += 1024u) {
+        const unsigned long long w = sys_load_b64(src + i);
         x ^= w;
         dst[i] = __longlong_as_double((long long)w);
       }
-      atomicXor(&s_x[0], (uint32_t)x);
-      atomicXor(&s_x[1], (uint32_t)(x >> 32));
+      x ^= want;  // (thread 1023 folds the sender's word in: the total must come out as the salt)
+      block_xor_into(s_x, x);
       __syncthreads();
-      if (t == 0) {
-        const unsigned long long want = __hip_atomic_load(src + pc.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((((unsigned long long)s_x[1] << 32 | s_x[0]) ^ (seq * 0x9E3779B97F4A7C15ull)) != want) {
-          if ((unsigned long long)wall_clock64() - t0 > X.timeout_ticks) s_bad = 1u;
-          else s_retry = 1u;
-        }
+      if (t == 0 && ((unsigned long long)s_x[1] << 32 | s_x[0]) != salt) {
+        if ((unsigned long long)wall_clock64() - t0 > X.timeout_ticks) s_bad = 1u;
+        else s_retry = 1u;
       }
       __syncthreads();
       if (!s_retry) break;
@@ -2059,12 +2148,17 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
     }
   }
   __syncthreads();
+  XSTAMP(5);
+#ifdef ABFT_DBG_STAMPS
+  if (t == 0)
+    for (int k = 0; k < 6; k++) sys_store_b64(ready + 256 + X.rank * 8 + k, st[k]);
+#endif
   if (t == 0) {
     if (s_bad) {
       if (X.nin > 0) full[X.in[0].vec_off] = __longlong_as_double(0x7ff8000000000000ll);
       __hip_atomic_store(fail + X.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __hip_atomic_store(done + X.rank, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    sys_store_b64(done + X.rank, seq);  // (every load of this block has returned: the barrier above)
     *X.counter = seq;
   }
 }

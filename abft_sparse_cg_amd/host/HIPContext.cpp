@@ -19,7 +19,7 @@ HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
     r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
     fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false), fuse_allreduce_(false),
-    one_node_(false), xchg_map_(NULL), xchg_bytes_(0), peer_xchg_ok_(false)
+    one_node_(false), xchg_map_(NULL), xchg_bytes_(0), peer_xchg_ok_(false), has_interior_(false), fixed_beside_(false)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
   replayed_[0] = replayed_[1] = false;
@@ -481,6 +481,7 @@ void HIPContextBase::adopt_plan(cg_matrix *M, const ShardPlan &plan)
   long long least = 2ll << 20;
   if (const char *env = getenv("ABFT_CG_OVERLAP_BYTES")) least = atoll(env);
   overlap_ = interior && incoming * 8 >= least;
+  has_interior_ = interior;
   setup_peer_exchange();
   if (getenv("ABFT_HIP_VERBOSE"))
     fprintf(stderr, "hip backend: rank %d of %d: %s [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
@@ -620,7 +621,7 @@ void HIPContextBase::exchange_begin(cg_vector *v)
 {
   if (peer_xchg_ok_)
   {
-    check(abft_hip_peer_exchange(ctx_, v->full), "abft_hip_peer_exchange");
+    check(abft_hip_peer_exchange_begin(ctx_, v->full, fixed_beside_ ? 1 : 0), "abft_hip_peer_exchange_begin");
     return;
   }
   if (!comm_->device_collectives())
@@ -651,7 +652,10 @@ void HIPContextBase::exchange_begin(cg_vector *v)
 void HIPContextBase::exchange_finish(cg_vector *v)
 {
   if (peer_xchg_ok_)
+  {
+    check(abft_hip_peer_exchange_finish(ctx_), "abft_hip_peer_exchange_finish");
     return;
+  }
   if (comm_->device_collectives())
   {
     comm_->device_exchange_finish(abft_hip_get_stream(ctx_));
@@ -793,12 +797,12 @@ void HIPContextBase::fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, c
   {
     const int off = comm_->rank() * slot_;
     exchange_begin(p);
-    if (overlap_)
+    if (overlap_ || fixed_beside_)
       check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw, ABFT_PART_INTERIOR),
             "abft_hip_spmv_dot_part_dev");
     exchange_finish(p);
     check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw,
-                                     overlap_ ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
+                                     (overlap_ || fixed_beside_) ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
           "abft_hip_spmv_dot_part_dev");
     device_allreduce(pw);
   }
@@ -855,6 +859,14 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
   // use, which must not happen under capture.
   bool graph = !comm_ || comm_->device_collectives() || (peers_ok_ && peer_xchg_ok_);
   if (const char *env = getenv("ABFT_CG_GRAPH")) graph = graph && strcmp(env, "0") != 0;
+  // ABFT_CG_EXCHANGE_BESIDE=1: replayed, the window exchange runs on a graph branch of its own next to
+  // the rows that read no window.  Off by default: a branch is two stream hand-offs at replay too, and
+  // with two ranks sharing the one GPU that could be measured on it cost more than the 14 us it hides
+  // (laplace5:1500,1500, 2 ranks: 268 vs 217 us per iteration)
+  {
+    const char *env = getenv("ABFT_CG_EXCHANGE_BESIDE");
+    fixed_beside_ = graph && comm_ && peer_xchg_ok_ && has_interior_ && env && !strcmp(env, "1");
+  }
   int done = 0;
   const int total = warmup + steps;
   double t0 = 0.0;
@@ -885,6 +897,7 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
           fprintf(stderr, "hip backend: hipGraph capture of the CG iteration failed (%s); running eagerly\n",
                   abft_hip_last_error());
           graph = false;
+          fixed_beside_ = false;
           fixed_graph_[parity] = NULL;
           fixed_iteration(A, x, r, p, w, parity);
           done++;
@@ -945,6 +958,7 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     check(abft_hip_peer_board_fuse(ctx_, 0), "abft_hip_peer_board_fuse");
     fuse_allreduce_ = false;
   }
+  fixed_beside_ = false;
   if (comm_ || v[1] > 0.0)
     report_events(true);  // collective across ranks: every rank calls it
   if (seconds) *seconds = dt;

@@ -133,6 +133,8 @@ private:
   void *xchg_map_;               // shared mapping behind the window exchange (NULL: not in use)
   size_t xchg_bytes_;
   bool peer_xchg_ok_;            // the windows of this matrix travel through shared host memory
+  bool has_interior_;            // the shard has rows that read no other rank's slot
+  bool fixed_beside_;            // run_fixed under graph replay: the window exchange next to those rows
 };
 
 template<int FORMAT, int MODE>

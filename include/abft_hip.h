@@ -263,6 +263,12 @@ int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, size_t bytes,
                                   const abft_peer_piece *in, int nin, double timeout_seconds);
 int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx);
 int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full);
+/* ... or, with beside != 0, on a side stream behind everything enqueued so far: what the caller
+ * enqueues on the context's stream until _finish runs next to the exchange (an SpMV's rows that
+ * read no window: abft_hip_spmv_dot_part_dev, ABFT_PART_INTERIOR); _finish makes the context's
+ * stream wait for it.  Inside a captured graph the two hand-offs are edges, not host work. */
+int abft_hip_peer_exchange_begin(abft_hip_ctx *ctx, abft_hip_vector *full, int beside);
+int abft_hip_peer_exchange_finish(abft_hip_ctx *ctx);
 int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx);
 
 /* Device-scalar forms, for loops that keep alpha and beta on the device (no host

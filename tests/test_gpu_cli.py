@@ -317,11 +317,12 @@ def test_bench_loop_fused_and_unfused_allreduces_same_bits():
     fused = run_ranks(3, args, ("--one-gpu",))
     apart = run_ranks(3, args, ("--one-gpu",), env={"ABFT_COMM_FUSE_ALLREDUCE": "0"})
     eager = run_ranks(3, args, ("--one-gpu",), env={"ABFT_CG_GRAPH": "0"})
+    inline = run_ranks(3, args, ("--one-gpu",), env={"ABFT_CG_EXCHANGE_BESIDE": "1"})  # the exchange on a graph branch of its own
     one = run("csr", args)
-    for p in (fused, apart, eager, one):
+    for p in (fused, apart, eager, inline, one):
         assert p.returncode == 0, p.stderr[-800:]
-    a, b, c, d = (bench_line(p.stdout) for p in (fused, apart, eager, one))
-    assert a[0] == b[0] == c[0] == 3 and a[4] == b[4] == c[4]
+    a, b, c, e, d = (bench_line(p.stdout) for p in (fused, apart, eager, inline, one))
+    assert a[0] == b[0] == c[0] == e[0] == 3 and a[4] == b[4] == c[4] == e[4]
     assert abs(a[4] - d[4]) <= 1e-10 * d[4]
 
 

@@ -21,8 +21,9 @@ Projection per iteration at G ranks:
     T_exchange = all-gather of 8 * slot bytes per rank over xGMI: each rank receives (G-1) slots,
                  one from each peer over its own link, concurrently: 8 * slot / (LINK_GBPS * EFF)
                  (banded matrices exchange halo windows of a few KB through shared host memory
-                 instead, one kernel: T_WINDOW_US, assumed)
-with LINK_GBPS = 153 (MI355X_MICROARCH.md: 7 links x ~153 GB/s), EFF = 0.7, T_WINDOW_US = 8.
+                 instead, one kernel: T_WINDOW_US = 14, measured between two streams of one GPU
+                 with windows of config 2's size, tools/peer_latency.py)
+with LINK_GBPS = 153 (MI355X_MICROARCH.md: 7 links x ~153 GB/s), EFF = 0.7.
 Prints a markdown table (commit it under profiles/)."""
 import argparse
 import ctypes as C
@@ -37,7 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-LINK_GBPS, EFF, T_WINDOW_US = 153.0, 0.7, 8.0
+LINK_GBPS, EFF, T_WINDOW_US = 153.0, 0.7, 14.0
 
 
 def shard(spec, G, k):
