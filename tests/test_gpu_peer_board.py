@@ -223,3 +223,29 @@ def test_all_reduce_in_the_tail_of_the_reductions(pair_of_contexts):
         capi.check(L.abft_hip_peer_board_fuse(c.h, 0))
     assert L.abft_hip_peer_board_fuse(ctxs[0].h, 1) == 0 and L.abft_hip_peer_board_detach(ctxs[0].h) == 0
     assert L.abft_hip_peer_board_fuse(ctxs[0].h, 1) != 0  # not attached any more
+
+
+def test_one_way_windows_wait_for_the_reader_before_reusing_an_outbox(two_ranks_with_outboxes):
+    """rank 0 sends, rank 1 only receives: nothing rank 0 waits for tells it that rank 1 is through
+    with an outbox, so from the third exchange on it asks (the `done` word) before overwriting one"""
+    L, capi, ctxs, addr, nbytes, box = two_ranks_with_outboxes
+    n = 300
+    capi.check(L.abft_hip_peer_exchange_attach(ctxs[0].h, addr[0], nbytes, 0, 2, box, pieces([(1, 5, n, 0)]), 1,
+                                               pieces([]), 0, 20.0))
+    capi.check(L.abft_hip_peer_exchange_attach(ctxs[1].h, addr[1], nbytes, 1, 2, box, pieces([]), 0,
+                                               pieces([(0, 5, n, 0)]), 1, 20.0))
+    full = [c.create_vector(1024) for c in ctxs]
+    rng = np.random.default_rng(2)
+    for k in range(6):
+        src = rng.standard_normal(1024)
+        ctxs[0].upload(full[0], src)
+        ctxs[1].upload(full[1], np.zeros(1024))
+        # the sender first, twice as often as not ahead of the reader
+        capi.check(L.abft_hip_peer_exchange(ctxs[0].h, full[0].h))
+        capi.check(L.abft_hip_peer_exchange(ctxs[1].h, full[1].h))
+        got = ctxs[1].download(full[1])
+        want = np.zeros(1024)
+        want[5:5 + n] = src[5:5 + n]
+        assert np.array_equal(got, want), k
+        assert np.array_equal(ctxs[0].download(full[0]), src)
+    assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
