@@ -160,26 +160,17 @@ void HIPContextBase::setup_peer_exchange()
   const int G = comm_->size(), me = comm_->rank();
   if (!one_node_ || !use_windows_ || G < 2)
     return;
-  // every sender's outbox: its windows in ascending reader order, 256-byte aligned
-  std::vector<abft_peer_piece> out, in;
-  size_t box = 0;
-  for (int g = 0; g < G; g++)
+  // every sender's outbox: its windows in ascending reader order (host/partition.cpp, CPU-tested)
+  std::vector<WindowPiece> wout, win;
+  const size_t box = plan_outboxes(all_need_, G, slot_, me, wout, win);
+  if (wout.size() > 63 || win.size() > 63)
+    return;
+  std::vector<abft_peer_piece> out(wout.size()), in(win.size());
+  for (size_t k = 0; k < wout.size() + win.size(); k++)
   {
-    size_t off = 0;
-    for (int q = 0; q < G; q++)
-    {
-      if (q == g) continue;
-      const int *w = &all_need_[2 * ((size_t)q * G + g)];  // what rank q reads of rank g's slot
-      if (w[1] <= w[0]) continue;
-      abft_peer_piece pc;
-      pc.count = (uint32_t)(w[1] - w[0]);
-      pc.vector_offset = (uint32_t)((size_t)g * slot_ + w[0]);
-      pc.box_offset = off;
-      if (g == me) { pc.peer = q; out.push_back(pc); }
-      if (q == me) { pc.peer = g; in.push_back(pc); }
-      off += (((size_t)pc.count + 1) * sizeof(double) + 255) & ~(size_t)255;  // (+ the library's check word)
-    }
-    box = std::max(box, off);
+    const WindowPiece &w = k < wout.size() ? wout[k] : win[k - wout.size()];
+    abft_peer_piece &pc = k < wout.size() ? out[k] : in[k - wout.size()];
+    pc.peer = w.peer; pc.vector_offset = w.vector_offset; pc.count = w.count; pc.box_offset = w.box_offset;
   }
   long long cap = 1ll << 20;
   if (const char *c = getenv("ABFT_COMM_WINDOW_BYTES")) cap = atoll(c);

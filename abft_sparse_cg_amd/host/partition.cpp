@@ -97,6 +97,55 @@ void plan_shard(int fmt, const uint32_t *columns, const uint32_t *rows, const do
   p.interior_hi = interior ? best_hi : 0;
 }
 
+size_t plan_outboxes(const std::vector<int> &all_need, int ranks, int slot, int me, std::vector<WindowPiece> &out,
+                     std::vector<WindowPiece> &in)
+{
+  out.clear();
+  in.clear();
+  size_t box = 0;
+  for (int g = 0; g < ranks; g++)
+  {
+    size_t off = 0;
+    for (int q = 0; q < ranks; q++)
+    {
+      if (q == g) continue;
+      const int *w = &all_need[2 * ((size_t)q * ranks + g)];  // what rank q reads of rank g's slot
+      if (w[1] <= w[0]) continue;
+      WindowPiece pc;
+      pc.count = (uint32_t)(w[1] - w[0]);
+      pc.vector_offset = (uint32_t)((size_t)g * slot + w[0]);
+      pc.box_offset = off;
+      if (g == me) { pc.peer = q; out.push_back(pc); }
+      if (q == me) { pc.peer = g; in.push_back(pc); }
+      off += (((size_t)pc.count + 1) * sizeof(double) + 255) & ~(size_t)255;  // (+ the library's check word)
+    }
+    box = std::max(box, off);
+  }
+  return box;
+}
+
+extern "C" long long abft_plan_outboxes(const int *all_need, int ranks, int slot, int me, long long *out, int *nout,
+                                        long long *in, int *nin, int cap)
+{
+  if (ranks < 1 || me < 0 || me >= ranks || slot < 0 || !all_need) return -1;
+  std::vector<int> need(all_need, all_need + 2 * (size_t)ranks * ranks);
+  std::vector<WindowPiece> o, i;
+  const size_t box = plan_outboxes(need, ranks, slot, me, o, i);
+  for (int pass = 0; pass < 2; pass++)
+  {
+    const std::vector<WindowPiece> &v = pass ? i : o;
+    long long *dst = pass ? in : out;
+    for (size_t k = 0; k < v.size() && (int)k < cap && dst; k++)
+    {
+      dst[4 * k] = v[k].peer; dst[4 * k + 1] = v[k].vector_offset; dst[4 * k + 2] = v[k].count;
+      dst[4 * k + 3] = (long long)v[k].box_offset;
+    }
+  }
+  if (nout) *nout = (int)o.size();
+  if (nin) *nin = (int)i.size();
+  return (long long)box;
+}
+
 extern "C" int abft_plan_shard(int fmt, const uint32_t *columns, const uint32_t *rows, const double *values,
                                long long nnz, int N, int ranks, int me, int *bounds, long long *scalars, int *need,
                                uint32_t *lout, uint32_t *pin, uint32_t *gidx, long long cap)

@@ -45,7 +45,26 @@ void plan_bounds_counts(const std::vector<long long> &per_output, int N, int ran
 void plan_shard(int fmt, const uint32_t *columns, const uint32_t *rows, const double *values, size_t elem0,
                 size_t count, int N, const std::vector<int> &bounds, int me, ShardPlan &plan);
 
+// The halo windows as they travel through shared host memory (include/abft_hip.h,
+// abft_hip_peer_exchange_*): every rank lays the windows its peers read out in an outbox -- in
+// ascending reader order, each followed by the library's 8-byte check word, 256-byte aligned --
+// and since `all_need` (ranks * ranks windows: [2 * (q * ranks + g)] = what rank q reads of rank
+// g's slot) is known to every rank, all of them compute the same layout without talking.
+struct WindowPiece
+{
+  int peer;              // out: the reader; in: the sender
+  uint32_t vector_offset, count;   // doubles from the start of the gathered vector
+  uint64_t box_offset;   // bytes from the start of the SENDER's outbox
+};
+// returns the outbox size every rank uses (the largest rank's; 0: no windows at all)
+size_t plan_outboxes(const std::vector<int> &all_need, int ranks, int slot, int me, std::vector<WindowPiece> &out,
+                     std::vector<WindowPiece> &in);
+
 extern "C" {
+// ctypes view of plan_outboxes: pieces as 4 x int64 {peer, vector_offset, count, box_offset}; returns the
+// outbox size, *nout / *nin the piece counts (at most `cap` of each are written)
+long long abft_plan_outboxes(const int *all_need, int ranks, int slot, int me, long long *out, int *nout, long long *in,
+                             int *nin, int cap);
 // ctypes view for the CPU tests: returns 0, fills bounds[ranks+1], scalars[8] = {slot, n_pad, out0,
 // n_loc, local nnz, first, interior_lo, interior_hi}, need[2*ranks]; lout/pin/gidx (each `cap`
 // entries, may be NULL) receive the local element arrays.

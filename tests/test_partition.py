@@ -131,3 +131,64 @@ def test_planner_awkward_shapes():
     rc = L.abft_plan_shard(0, cols.ctypes.data_as(u32p), rows.ctypes.data_as(u32p), vals.ctypes.data_as(C.POINTER(C.c_double)),
                            C.c_longlong(8), 7, 8, 0, None, None, None, None, None, None, C.c_longlong(0))
     assert rc == 1  # more ranks than rows: refused (the backend exits with a message)
+
+
+@pytest.mark.parametrize("fmt", [0, 1])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_outbox_layout_of_the_window_exchange(fmt, world):
+    """host/partition.cpp plan_outboxes: how the halo windows are laid out in the senders' outboxes for
+    the exchange through shared host memory (abft_hip_peer_exchange_*).  Every rank computes it alone
+    from the windows all ranks know; here: both ends of every window agree, windows (+ their check
+    word) do not overlap inside an outbox, all fit the common outbox size, and a host-side replay of
+    the exchange -- copy out, copy in -- delivers exactly the entries every rank's SpMV reads."""
+    import ctypes as C
+    from _partition_worker import plan
+    cols, rows, vals, n = laplace5(31, 47)
+    L = lib()
+    L.abft_plan_outboxes.restype = C.c_longlong
+    plans = [plan(L, fmt, cols, rows, vals, n, world, me) for me in range(world)]
+    slot = plans[0]["slot"]
+    need = np.zeros((world, world, 2), dtype=np.int32)  # [reader][owner] = window of the owner's slot
+    for q, p in enumerate(plans):
+        for g in range(world):
+            need[q, g] = p["need"][g] if g != q else (0, 0)
+    flat = np.ascontiguousarray(need.reshape(-1))
+    layouts, boxes = [], set()
+    for me in range(world):
+        out = np.zeros(4 * 64, dtype=np.int64)
+        inn = np.zeros(4 * 64, dtype=np.int64)
+        no, ni = C.c_int(), C.c_int()
+        box = L.abft_plan_outboxes(flat.ctypes.data_as(C.POINTER(C.c_int)), world, slot, me,
+                                   out.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(no),
+                                   inn.ctypes.data_as(C.POINTER(C.c_longlong)), C.byref(ni), 64)
+        boxes.add(box)
+        layouts.append((out[:4 * no.value].reshape(-1, 4), inn[:4 * ni.value].reshape(-1, 4)))
+    assert len(boxes) == 1 and min(boxes) > 0  # the same outbox size on every rank
+    box = boxes.pop()
+    for me, (out, inn) in enumerate(layouts):
+        spans = sorted((int(o[3]), int(o[3]) + 8 * (int(o[2]) + 1)) for o in out)
+        assert all(a1 <= b0 for (_, a1), (b0, _) in zip(spans, spans[1:])) and (not spans or spans[-1][1] <= box)
+        assert all(int(o[3]) % 256 == 0 and 0 <= o[0] < world and o[0] != me for o in out)
+        for peer, voff, count, boff in inn:  # the sender lists the same window, for me, at the same place
+            theirs = layouts[peer][0]
+            assert any(t[0] == me and t[1] == voff and t[2] == count and t[3] == boff for t in theirs)
+            assert voff == peer * slot + need[me, peer, 0] and count == need[me, peer, 1] - need[me, peer, 0]
+        assert len(inn) == sum(1 for g in range(world) if g != me and need[me, g, 1] > need[me, g, 0])
+    # replay on the host: every rank's gathered vector ends up holding what its shard reads
+    x = rhs(n, 7)
+    b = plans[0]["bounds"]
+    full = [np.full(slot * world, np.nan) for _ in range(world)]
+    for g in range(world):
+        full[g][g * slot:g * slot + b[g + 1] - b[g]] = x[b[g]:b[g + 1]]
+    outboxes = [np.zeros(box // 8) for _ in range(world)]
+    for me, (out, _) in enumerate(layouts):
+        for peer, voff, count, boff in out:
+            outboxes[me][boff // 8:boff // 8 + count] = full[me][voff:voff + count]
+    for me, (_, inn) in enumerate(layouts):
+        for peer, voff, count, boff in inn:
+            full[me][voff:voff + count] = outboxes[peer][boff // 8:boff // 8 + count]
+    for me, p in enumerate(plans):
+        got = full[me][p["pin"]]
+        owner = p["pin"] // slot
+        assert not np.any(np.isnan(got))
+        assert np.array_equal(got, x[np.asarray(b)[owner] + p["pin"] % slot])
