@@ -219,6 +219,44 @@ __device__ void coo_fixup_body(const FixArgs &fx);
 // All-reduce of {v0, v1} (held by thread 0) across the ranks of a peer board, by every thread
 // of the calling block: see peer_allreduce_kernel below for the protocol.  Thread 0 returns
 // the sums in rank order; a rank that gives up waiting gets NaN and raises its flag.
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// Accesses to the shared region that go to memory whatever the caches hold (sc0 sc1: system
+// coherence level), 16 bytes wide: the compiler has no 16-byte system-scope atomic, and 8-byte
+// ones cross the link one request per lane.  No fences anywhere in this kernel -- a system-scope
+// release writes back every dirty line of the XCD's L2 first (the vectors the iteration has just
+// written) -- the order comes from waiting for the stores (vmcnt) before the flag is stored.
+__device__ __forceinline__ void sys_store_b128(u64x2 *p, u64x2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void sys_store_b64(unsigned long long *p, unsigned long long v) {
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void sys_load4_b128(const u64x2 *p0, const u64x2 *p1, const u64x2 *p2, const u64x2 *p3,
+                                               u64x2 &w0, u64x2 &w1, u64x2 &w2, u64x2 &w3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+__device__ __forceinline__ void sys_load2_b128(const u64x2 *p0, const u64x2 *p1, u64x2 &w0, u64x2 &w1) {
+  asm volatile(
+      "global_load_dwordx4 %0, %2, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %3, off sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(w0), "=&v"(w1)
+      : "v"(p0), "v"(p1)
+      : "memory");
+}
+__device__ __forceinline__ unsigned long long sys_load_b64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __device__ __forceinline__ unsigned long long peer_check_word(unsigned long long seq, double v0, double v1) {
   return (seq * 0x9E3779B97F4A7C15ull) ^ (unsigned long long)__double_as_longlong(v0) ^
          ((unsigned long long)__double_as_longlong(v1) << 1 | (unsigned long long)__double_as_longlong(v1) >> 63);
@@ -232,36 +270,35 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
   if (t == 0) {
     const unsigned long long seq = *P.counter + 1ull;  // written by the previous all-reduce on this stream
     PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
-    __hip_atomic_store(&mine->v0, (unsigned long long)__double_as_longlong(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&mine->v1, (unsigned long long)__double_as_longlong(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // (a word that ties the three together: a reader that sees the new sequence number next to an
-    // old value -- stores overtaking each other on the way, which the release below forbids -- keeps polling)
-    __hip_atomic_store(&mine->pad, peer_check_word(seq, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // (no release fence: it would first write back every dirty line of this XCD's L2 -- the vector the
-    // reduction's kernel has just written; the stores above are write-through and have been waited for)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&mine->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // two 16-byte stores, {v0, v1} and {sequence number, check word}, not waited for and in no
+    // particular order: a reader takes a slot only when its check word fits the sequence number AND
+    // the values next to it, so it cannot pair a new number with an old value; it polls whole slots,
+    // which makes an all-reduce one store and (mostly) one load across the link instead of a store,
+    // its acknowledgement, a flag, a poll and a load
+    u64x2 *half = reinterpret_cast<u64x2 *>(mine);
+    sys_store_b128(half, u64x2{(unsigned long long)__double_as_longlong(v0), (unsigned long long)__double_as_longlong(v1)});
+    sys_store_b128(half + 1, u64x2{seq, peer_check_word(seq, v0, v1)});
     s_pseq = seq;
     s_pbad = 0u;
   }
   __syncthreads();
   const unsigned long long seq = s_pseq;
   if (t < (uint32_t)P.size) {
-    const PeerSlot *slot = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + t;
+    const u64x2 *half = reinterpret_cast<const u64x2 *>(P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + t);
     const unsigned long long t0 = (unsigned long long)wall_clock64();
     bool ok = false;
     double a = 0.0, b = 0.0;
     for (;;) {
-      if (__hip_atomic_load(&slot->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) {
-        a = __longlong_as_double((long long)__hip_atomic_load(&slot->v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-        b = __longlong_as_double((long long)__hip_atomic_load(&slot->v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-        if (__hip_atomic_load(&slot->pad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == peer_check_word(seq, a, b)) {
-          ok = true;
-          break;
-        }
+      u64x2 val, tag;
+      sys_load2_b128(half, half + 1, val, tag);
+      a = __longlong_as_double((long long)val.x);
+      b = __longlong_as_double((long long)val.y);
+      if (tag.x == seq && tag.y == peer_check_word(seq, a, b)) {
+        ok = true;
+        break;
       }
       if ((unsigned long long)wall_clock64() - t0 > P.timeout_ticks) break;
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(2);
     }
     if (!ok) {
       a = b = 0.0;
@@ -1973,35 +2010,6 @@ hipError_t launch_peer_allreduce(double *pair, const PeerArgs &P, hipStream_t s)
 // sequence number; before a rank overwrites an outbox it waits until its readers have
 // finished with the exchange two back (`done`), so the protocol does not lean on whatever
 // else synchronises the ranks in between.  Capturable, bounded waits, NaN + flag on give-up.
-typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-
-// Accesses to the shared region that go to memory whatever the caches hold (sc0 sc1: system
-// coherence level), 16 bytes wide: the compiler has no 16-byte system-scope atomic, and 8-byte
-// ones cross the link one request per lane.  No fences anywhere in this kernel -- a system-scope
-// release writes back every dirty line of the XCD's L2 first (the vectors the iteration has just
-// written) -- the order comes from waiting for the stores (vmcnt) before the flag is stored.
-__device__ __forceinline__ void sys_store_b128(u64x2 *p, u64x2 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void sys_store_b64(unsigned long long *p, unsigned long long v) {
-  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void sys_load4_b128(const u64x2 *p0, const u64x2 *p1, const u64x2 *p2, const u64x2 *p3,
-                                               u64x2 &w0, u64x2 &w1, u64x2 &w2, u64x2 &w3) {
-  asm volatile(
-      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
-      "global_load_dwordx4 %1, %5, off sc0 sc1\n\t"
-      "global_load_dwordx4 %2, %6, off sc0 sc1\n\t"
-      "global_load_dwordx4 %3, %7, off sc0 sc1\n\t"
-      "s_waitcnt vmcnt(0)"
-      : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
-      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
-      : "memory");
-}
-__device__ __forceinline__ unsigned long long sys_load_b64(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 __device__ __forceinline__ bool peer_wait_ge(const unsigned long long *word, unsigned long long want,
                                              unsigned long long timeout_ticks) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
