@@ -166,7 +166,7 @@ static int ev_cmp(const void *a, const void *b) {
 }
 
 int ora_events(ora_matrix *m, ora_event *buf, int cap, int *fatal) {
-  qsort(m->ev, (size_t)m->nev, sizeof(ora_event), ev_cmp);
+  if (m->nev > 0) qsort(m->ev, (size_t)m->nev, sizeof(ora_event), ev_cmp);  /* (no events: the array may not exist yet) */
   int n = 0, f = 0;
   for (int i = 0; i < m->nev && n < cap; i++) {
     buf[n++] = m->ev[i];

@@ -30,3 +30,12 @@ for n in 2 3 5; do
   echo "comm_test under ASan/UBSan, $n ranks: status $st, rank 0 says: $(tail -1 $T/out_0.txt)"
   [ $st -eq 0 ] || { cat $T/out_*.txt; exit 1; }
 done
+# the CPU oracle (oracle/abft_oracle.c: test infrastructure) against the golden vectors and the reference build
+O=$ROOT/oracle
+cp $O/libabft_oracle.so $T/oracle_orig.so
+trap 'cp $T/orig.so $ROOT/abft_sparse_cg_amd/libabft_host.so; cp $T/oracle_orig.so $O/libabft_oracle.so; rm -rf $T' EXIT
+gcc -O1 -g -ffp-contract=off -fopenmp -fPIC -Wall -fsanitize=address,undefined -fno-omit-frame-pointer -shared \
+    -o $O/libabft_oracle.so $O/abft_oracle.c
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" \
+    python -m pytest tests/test_oracle_golden.py tests/test_oracle_vs_ref.py -x -q -m "not gpu"
