@@ -11,6 +11,8 @@ by 2 bit-for-bit; CSR and COO give bit-identical y on a symmetric matrix (the
 reference's two executables do); x.(A z) = z.(A x); injected
 single-bit flips at full size are each reported once with the right global
 index, repaired in place, and leave y bit-identical to the fault-free y."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -163,6 +165,13 @@ def test_config4_random_csr_secded_full_size(amd, gen):
     r = Run(amd, "csr", "secded", mat)
     try:
         assert r.ctx.matrix_info(r.A) == ("sweep", 1)  # scattered columns over a 33 MB vector: one persistent launch
+        # panels sized so that the average segment (4096 rows x 25 per row x width / n) fills two 2048-element
+        # tiles less 1.5 standard deviations -- not a power of two
+        from abft_sparse_cg_amd import capi
+        npan, width = ctypes.c_int(), ctypes.c_int()
+        capi.check(capi.load().abft_hip_matrix_panels(r.A.h, ctypes.byref(npan), ctypes.byref(width)))
+        per_segment = 4096 * len(vals) / n * width.value / n
+        assert 3900 < per_segment < 4096 - 64 and npan.value == -(-n // width.value) and width.value % 16 == 0
         y = r.spmv(x)
         # strictly diagonally dominant rows: A.1 = 1 + (rounding of the row sum), checked in exact order on sample rows
         for row in (0, 17, n // 2, n - 1):
