@@ -122,6 +122,9 @@ struct CooDev {
 #ifndef ABFT_CFG_COO_PANEL_EPT
 #define ABFT_CFG_COO_PANEL_EPT 4  // 16-byte elements per thread per tile of the COO panel kernel
 #endif
+#ifndef ABFT_CFG_COO_SCHED_BARRIER
+#define ABFT_CFG_COO_SCHED_BARRIER 1  // bit m: COO kernels of mode m keep their streaming loads together (kernels.hip)
+#endif
 #ifndef ABFT_CFG_COO_PANEL_SHORT_SUMS
 #define ABFT_CFG_COO_PANEL_SHORT_SUMS 1  // COO panel kernel's ordered sums two-wide instead of four-wide
 #endif

@@ -459,6 +459,11 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
     ok[j] = valid;
   }
   double xv[EPT];
+  // (Measured and dropped: scheduling barriers around this loop so that all gathers of the tile go out
+  // before the first is used.  Left alone hipcc issues them one at a time in the sweep kernel with 8 and
+  // 16 rows per thread, each behind an s_waitcnt vmcnt(0) for the one before -- and that is the faster
+  // form there: 667 vs 745 us on config 4 with 16 rows per thread, 689 vs 675 with 8, no difference on
+  // the streaming kernel.  One gather in flight per lane from 16 waves already fills the CU's path to L2.)
 #pragma unroll
   for (int j = 0; j < EPT; j++) {
     const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
@@ -800,14 +805,19 @@ template <int EPT> struct CooTileRegs {
 };
 
 // the streaming loads of one COO tile [lo, hi): out-of-tile lanes re-read its first element
-template <int EPT>
+template <int MODE, int EPT>
 __device__ __forceinline__ void coo_issue_loads(const CooDev &A, uint32_t lo, uint32_t hi, CooTileRegs<EPT> &t) {
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
     t.e[s] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
   }
-  // (no scheduling barrier here, unlike csr_issue_loads: measured 3 % slower on this kernel)
+  // Keep every streaming load ahead of the first use.  Without this hipcc is free to put an element's
+  // range check right behind its load -- and in `none`, where nothing else sits between them, it does:
+  // load, s_waitcnt vmcnt(0), load, ... four HBM round trips per tile in a row (config 5 `none`: 227 us
+  // against 194 us in `sed`).  In the ECC modes the barrier measured 3 % slower (round 1), so it is
+  // per mode: ABFT_CFG_COO_SCHED_BARRIER bit m = mode m.
+  if ((ABFT_CFG_COO_SCHED_BARRIER >> MODE) & 1) __builtin_amdgcn_sched_barrier(0);
 }
 
 // ECC, gathers, products and columns -> LDS for a tile whose loads were issued into `t`;
@@ -886,7 +896,7 @@ __device__ __forceinline__ void coo_consume(const CooDev &A, const double *__res
 #endif
     xv[s] = in ? xv[s] : 0.0;
   }
-  if (prefetch) coo_issue_loads<EPT>(A, nlo, nhi, nxt);
+  if (prefetch) coo_issue_loads<MODE, EPT>(A, nlo, nhi, nxt);
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const double p = val[s] * xv[s];
@@ -899,7 +909,7 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
                                           const EventRing &ev, uint32_t lo, uint32_t hi,
                                           double *s_prod, uint32_t *s_col) {
   CooTileRegs<EPT> t, unused;
-  coo_issue_loads<EPT>(A, lo, hi, t);
+  coo_issue_loads<MODE, EPT>(A, lo, hi, t);
   coo_consume<MODE, EPT>(A, x, ev, lo, hi, t, s_prod, s_col, false, 0u, 0u, unused);
 }
 
