@@ -463,7 +463,8 @@ __device__ __forceinline__ void csr_consume(const CsrDev &A, const double *__res
   // before the first is used.  Left alone hipcc issues them one at a time in the sweep kernel with 8 and
   // 16 rows per thread, each behind an s_waitcnt vmcnt(0) for the one before -- and that is the faster
   // form there: 667 vs 745 us on config 4 with 16 rows per thread, 689 vs 675 with 8, no difference on
-  // the streaming kernel.  One gather in flight per lane from 16 waves already fills the CU's path to L2.)
+  // the streaming kernel -- and pinned in groups of 1, 2 or 4 it is 754 us all the same: what the barriers
+  // take away is the compiler's interleaving of one element's gather with the next element's checks.)
 #pragma unroll
   for (int j = 0; j < EPT; j++) {
     const bool in = ok[j] && col[j] < A.n_in;  // a corrupted index must never fault the GPU
