@@ -247,8 +247,9 @@ int abft_hip_peer_board_failed(abft_hip_ctx *ctx);
  * abft_hip_peer_exchange_bytes(size, outbox_bytes) mapped by every process; every rank lays
  * the windows it sends out in its outbox (`box_offset`, 8-byte aligned, the same
  * outbox_bytes on every rank; behind each window 8 more bytes belong to the library: a
- * check word) and lists the windows it receives with the offsets their senders chose.  `vector_offset` / `count` are in doubles from the start of the gathered
- * vector passed to abft_hip_peer_exchange.  Every rank must enqueue the same sequence of
+ * check word) and lists the windows it receives with the offsets their senders chose.
+ * `vector_offset` / `count` are in doubles from the start of the gathered vector passed to
+ * abft_hip_peer_exchange.  Every rank must enqueue the same sequence of
  * exchanges.  Give-up after `timeout_seconds` (<= 0: 120): NaN in the first received window
  * and abft_hip_peer_exchange_failed() = 1. */
 typedef struct {
@@ -266,7 +267,8 @@ int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full);
 /* ... or, with beside != 0, on a side stream behind everything enqueued so far: what the caller
  * enqueues on the context's stream until _finish runs next to the exchange (an SpMV's rows that
  * read no window: abft_hip_spmv_dot_part_dev, ABFT_PART_INTERIOR); _finish makes the context's
- * stream wait for it.  Inside a captured graph the two hand-offs are edges, not host work. */
+ * stream wait for it.  (Two stream hand-offs, also when replayed from a graph: worth it only
+ * for exchanges longer than those; the C++ host leaves it off) */
 int abft_hip_peer_exchange_begin(abft_hip_ctx *ctx, abft_hip_vector *full, int beside);
 int abft_hip_peer_exchange_finish(abft_hip_ctx *ctx);
 int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx);
