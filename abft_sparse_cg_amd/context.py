@@ -202,10 +202,10 @@ class HIPContext:
             check(self.L.abft_hip_spmv_part(self.h, mat.h, vec.h, result.h, part))
 
     def matrix_info(self, mat):
-        """-> (layout: 'stream' | 'panels' | 'sweep', kernel launches per spmv) -- measurement only"""
+        """-> (layout: 'stream' | 'panels' | 'sweep' | 'slice', kernel launches per spmv) -- measurement only"""
         lay, n = C.c_int(0), C.c_int(0)
         check(self.L.abft_hip_matrix_info(mat.h, C.byref(lay), C.byref(n)))
-        return ("stream", "panels", "sweep")[lay.value], n.value
+        return ("stream", "panels", "sweep", "slice")[lay.value], n.value
 
     def set_interior(self, mat, row_lo, row_hi):
         """rows [row_lo, row_hi) read nothing a peer still has to send (include/abft_hip.h)"""

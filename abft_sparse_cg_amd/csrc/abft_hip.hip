@@ -119,6 +119,9 @@ struct abft_hip_matrix {
   SweepLayout sweep{};
   int sweep_rpt = 8;
   uint32_t sweep_grid = 0, sweep_width = 0;
+  bool use_slice = false;           // slice layout (wave-private row sums in LDS; see SliceLayout)
+  SliceLayout slice{};
+  uint32_t slice_grid = 0, slice_width = 0;
   // streaming CSR: host copy of the row-block descriptors, and the tiles [t_lo, t_hi)
   // made of interior rows only (abft_hip_matrix_set_interior; empty by default)
   std::vector<uint4> blk_host;
@@ -630,6 +633,99 @@ static int finish_sweep(abft_hip_matrix *m, const SweepBuild &sb, uint32_t capac
   return ABFT_OK;
 }
 
+// ---- slice layout planning (host) ------------------------------------------------
+struct SliceBuild {
+  uint32_t nslices = 0, npanels = 0, width = 0, rows_log2 = 0;
+  std::vector<uint32_t> sub;       // nslices * (npanels + 1)
+  std::vector<uint16_t> rid;       // per stored element
+  std::vector<uint32_t> pos, orig; // caller's index -> storage position and back
+};
+
+// The slice layout's arrays (see SliceLayout).  Opt-in only (ABFT_HIP_LAYOUT=slice): measured slower than
+// the sweep layout on config 4 and on its 1/8 shard, kept for A/B runs and because it
+// has no limit on the elements of one row in one panel.  Needs a row's columns non-decreasing in the
+// caller's order (panels ascend).  `waves(rows_log2)`: waves of the kernel resident at once with slices
+// of that many rows.  ABFT_HIP_PANEL_WIDTH / ABFT_HIP_SLICE_ROWS / ABFT_HIP_SLICE_LAG override the geometry.
+template <typename Cap>
+static bool plan_slice(int mode, const uint32_t *cols, const uint32_t *rows, int n_out, int n_in, int nnz, Cap waves,
+                       SliceBuild &sb) {
+  const char *env = getenv("ABFT_HIP_LAYOUT");
+  if (!env || strcmp(env, "slice") || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0) return false;
+  const bool force = true;
+  for (int i = 1; i < nnz; i++)
+    if (rows[i] == rows[i - 1] && cols[i] < cols[i - 1]) return false;  // would reorder a row's additions
+  // rows per slice: the smallest power of two (64..1024) with which every slice has a wave of its
+  // own at once; beyond that, 512 and several rounds
+  uint32_t lg = 6;
+  while (lg < 10 && ((uint64_t)n_out + (1u << lg) - 1) >> lg > waves(lg)) lg++;
+  if (((uint64_t)n_out + (1u << lg) - 1) >> lg > waves(lg)) lg = 9;
+  if (const char *r = getenv("ABFT_HIP_SLICE_ROWS")) {
+    const long v = atol(r);
+    for (uint32_t k = 4; k <= 11; k++)
+      if (v == (1L << k)) lg = k;
+  }
+  uint32_t width = 1u << 17;  // entries of the gathered vector per panel (1 MB of it)
+  if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
+  const uint64_t npanels = ((uint64_t)n_in + width - 1) / width;
+  const uint64_t nslices = ((uint64_t)n_out + (1u << lg) - 1) >> lg;
+  if (npanels == 0 || nslices * (npanels + 1) > ((uint64_t)1 << 28)) return false;
+  if (!force && nslices * (npanels + 1) * 4u > (uint64_t)nnz * 3u) return false;  // the table must stay small next to the matrix
+  sb.nslices = (uint32_t)nslices; sb.npanels = (uint32_t)npanels; sb.width = width; sb.rows_log2 = lg;
+  auto panel_of = [&](int i) { return std::min<uint64_t>(cols[i] / width, npanels - 1); };
+  sb.sub.assign(nslices * (npanels + 1), 0);
+  // counts per (slice, panel) into sub[s][c + 1] ... then running bases
+  std::vector<uint32_t> cnt(nslices * npanels, 0);
+  for (int i = 0; i < nnz; i++) cnt[(uint64_t)(rows[i] >> lg) * npanels + panel_of(i)]++;
+  uint32_t run = 0;
+  for (uint64_t s = 0; s < nslices; s++) {
+    for (uint64_t c = 0; c < npanels; c++) {
+      sb.sub[s * (npanels + 1) + c] = run;
+      run += cnt[s * npanels + c];
+    }
+    sb.sub[s * (npanels + 1) + npanels] = run;
+  }
+  // placement in the caller's order: inside a (slice, panel) run rows ascend and a row's elements keep their order
+  sb.pos.resize((size_t)nnz);
+  sb.orig.resize((size_t)nnz);
+  sb.rid.assign((size_t)nnz + 2, 0);
+  std::fill(cnt.begin(), cnt.end(), 0);
+  for (int i = 0; i < nnz; i++) {
+    const uint64_t s = rows[i] >> lg, c = panel_of(i);
+    const uint32_t p = sb.sub[s * (npanels + 1) + c] + cnt[s * npanels + c]++;
+    sb.pos[i] = p;
+    sb.orig[p] = (uint32_t)i;
+    sb.rid[p] = (uint16_t)(rows[i] - (uint32_t)(s << lg) + 1u);  // 0 = no element (what a load past the end returns)
+  }
+  return true;
+}
+
+static int finish_slice(abft_hip_matrix *m, const SliceBuild &sb, uint32_t waves) {
+  int rc;
+  uint32_t *d_sub = nullptr, *d_pace = nullptr;
+  uint16_t *d_rid = nullptr;
+  if ((rc = dev_upload(m, &d_sub, sb.sub.data(), sb.sub.size(), sb.sub.size())) ||
+      (rc = dev_upload(m, &d_rid, sb.rid.data(), sb.rid.size(), sb.rid.size())))
+    return rc;
+  std::vector<uint32_t> init(8 * 256, 0xffffffffu);
+  if ((rc = dev_upload(m, &d_pace, init.data(), init.size(), init.size()))) return rc;
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));  // `init` goes out of scope
+  // all slices resident if they fit; else equal rounds
+  const uint32_t groups = (sb.nslices + 3u) / 4u, cap = std::max(waves / 4u, 1u);
+  const uint32_t rounds = (groups + cap - 1) / cap;
+  m->slice_grid = (groups + rounds - 1) / rounds;
+  m->use_slice = true;
+  m->slice_width = sb.width;
+  m->slice.sub = d_sub;
+  m->slice.rid = d_rid;
+  m->slice.nslices = sb.nslices;
+  m->slice.npanels = sb.npanels;
+  m->slice.rows_log2 = sb.rows_log2;
+  m->slice.pace = d_pace;
+  m->slice.lag = 2;
+  if (const char *e = getenv("ABFT_HIP_SLICE_LAG")) m->slice.lag = (uint32_t)std::max(0L, atol(e));
+  return ABFT_OK;
+}
+
 static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, const uint32_t *rows,
                       const double *values, int n_out, int n_in, int nnz, uint32_t index_base,
                       abft_hip_matrix **out) {
@@ -669,12 +765,34 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
 
   // ---- layout: streaming row blocks (default), or for scattered x the sweep layout
   // ---- (ABFT_HIP_LAYOUT=panels: its chunked-launch predecessor, kept for A/B runs) ----
+  SliceBuild lb;
+  auto slice_waves = [&](uint32_t lg) { return (uint64_t)spmv_slice_blocks_per_cu(mode, lg) * 4u * (uint64_t)ctx->num_cus; };
+  const bool slice = plan_slice(mode, columns, rows, n_out, n_in, nnz, slice_waves, lb);
   SweepBuild sb;
   auto cap = [&](int rpt) { return (uint64_t)spmv_sweep_blocks_per_cu(mode, rpt) * (uint64_t)ctx->num_cus; };
-  const bool sweep = plan_sweep(mode, columns, rows, n_out, n_in, nnz, cap, sb);
+  const bool sweep = !slice && plan_sweep(mode, columns, rows, n_out, n_in, nnz, cap, sb);
   PanelBuild pb;
-  const bool panels = !sweep && plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);
-  if (sweep) {
+  const bool panels = !slice && !sweep && plan_panels(mode, columns, rows, n_out, n_in, nnz, pb);
+  if (slice) {
+    std::vector<uint32_t> pcols((size_t)nnz);
+    std::vector<double> pvals((size_t)nnz);
+    for (int i = 0; i < nnz; i++) {
+      pcols[lb.pos[i]] = columns[i];
+      pvals[lb.pos[i]] = values[i];
+    }
+    uint32_t *d_orig = nullptr, *d_pos = nullptr;
+    if ((rc = dev_upload(m, &A.cols, pcols.data(), (size_t)nnz, padded)) ||
+        (rc = dev_upload(m, &A.vals, pvals.data(), (size_t)nnz, padded)) ||
+        (rc = dev_upload(m, &d_orig, lb.orig.data(), (size_t)nnz, (size_t)nnz)) ||
+        (rc = dev_upload(m, &d_pos, lb.pos.data(), (size_t)nnz, (size_t)nnz)) ||
+        (rc = finish_slice(m, lb, (uint32_t)slice_waves(lb.rows_log2)))) {
+      matrix_free(m);
+      return rc;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // pcols/pvals go out of scope
+    A.orig_index = d_orig;
+    A.pos_of_orig = d_pos;
+  } else if (sweep) {
     std::vector<uint32_t> pcols((size_t)nnz);
     std::vector<double> pvals((size_t)nnz);
     for (int i = 0; i < nnz; i++) {
@@ -731,7 +849,7 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   }
   A.rowptr = d_rowptr;
   A.blk = d_blk;
-  if (!panels && !sweep) m->blk_host = blk;
+  if (!panels && !sweep && !slice) m->blk_host = blk;
   hipError_t e = launch_encode_csr(mode, A.cols, A.vals, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // host arrays may be freed on return
   if (e != hipSuccess) {
@@ -861,7 +979,7 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
   if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
     // one partial per SpMV workgroup: row blocks (streaming) or output groups (panels)
     const uint32_t max_parts = std::max({nblk, m->use_panels ? std::max(m->panel_grid, m->panels.ngroups) : 0u,
-                                         m->use_sweep ? m->sweep_grid : 0u});
+                                         m->use_sweep ? m->sweep_grid : 0u, m->use_slice ? m->slice_grid : 0u});
     if (hipMalloc((void **)&m->fuse_partials, (size_t)std::max<uint32_t>(max_parts, 1) * sizeof(double)) != hipSuccess) {
       matrix_free(m);
       *out = nullptr;
@@ -928,7 +1046,7 @@ extern "C" int abft_hip_matrix_set_interior(abft_hip_matrix *mat, int row_lo, in
 
 extern "C" int abft_hip_matrix_info(abft_hip_matrix *mat, int *layout, int *launches_per_spmv) {
   if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
-  if (layout) *layout = mat->use_sweep ? 2 : mat->use_panels ? 1 : 0;
+  if (layout) *layout = mat->use_slice ? 3 : mat->use_sweep ? 2 : mat->use_panels ? 1 : 0;
   if (launches_per_spmv) {
     int n = 1;
     if (mat->use_panels && mat->panel_chunk && mat->panels.npanels)
@@ -954,7 +1072,7 @@ extern "C" int abft_hip_matrix_read_csr(abft_hip_matrix *mat, uint32_t *cols, ui
   hipStream_t s = mat->ctx->stream;
   const CsrDev &A = mat->csr;
   if (rowptr) HIPCHK(hipMemcpyAsync(rowptr, A.rowptr, ((size_t)A.n_out + 1) * 4, hipMemcpyDeviceToHost, s));
-  if (!mat->use_panels && !mat->use_sweep) {
+  if (!mat->use_panels && !mat->use_sweep && !mat->use_slice) {
     if (cols && A.nnz) HIPCHK(hipMemcpyAsync(cols, A.cols, (size_t)A.nnz * 4, hipMemcpyDeviceToHost, s));
     if (values && A.nnz) HIPCHK(hipMemcpyAsync(values, A.vals, (size_t)A.nnz * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1553,7 +1671,7 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   if (part == ABFT_PART_INTERIOR && n_int == 0) return ABFT_OK;  // nothing to run ahead of the exchange
   // a range of column panels (layouts that sweep panels): [c0, c1) of them, the sums of an
   // earlier range carried in `result`; the fused product belongs to the range that ends the sweep
-  const uint32_t npan = mat->use_sweep ? mat->sweep.npanels : 1u;  // (the other layouts run whole)
+  const uint32_t npan = mat->use_sweep ? mat->sweep.npanels : mat->use_slice ? mat->slice.npanels : 1u;  // (the other layouts run whole)
   const bool whole = c1 < 0;
   if (whole) { c0 = 0; c1 = (int)npan; }
   if (c0 < 0 || c0 >= c1 || (uint32_t)c1 > npan) return set_err(ABFT_ERR_INVALID, "spmv: panels [%d,%d) outside [0,%u)", c0, c1, npan);
@@ -1576,7 +1694,11 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   FixArgs fix{};
   {
     KernelTimer t(ctx, ABFT_K_SPMV);
-    if (mat->use_sweep) {
+    if (mat->use_slice) {
+      nparts = mat->slice_grid;
+      HIPCHK(launch_spmv_slice(mat->mode, mat->csr, mat->slice, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr,
+                               mat->slice_grid, (uint32_t)c0, (uint32_t)c1, ctx->stream));
+    } else if (mat->use_sweep) {
       nparts = mat->sweep_grid;
       HIPCHK(launch_spmv_sweep(mat->mode, mat->sweep_rpt, mat->csr, mat->sweep, vec->d, result->d, ctx->ring,
                                do_fuse ? &fuse : nullptr, mat->sweep_grid, (uint32_t)c0, (uint32_t)c1, ctx->stream));
@@ -1633,8 +1755,9 @@ extern "C" int abft_hip_spmv_dot_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, co
 
 extern "C" int abft_hip_matrix_panels(abft_hip_matrix *mat, int *npanels, int *width) {
   if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
-  if (npanels) *npanels = mat->use_sweep ? (int)mat->sweep.npanels : 1;
-  if (width) *width = mat->use_sweep ? (int)mat->sweep_width : (int)(mat->fmt == ABFT_FMT_CSR ? mat->csr.n_in : mat->coo.n_in);
+  if (npanels) *npanels = mat->use_sweep ? (int)mat->sweep.npanels : mat->use_slice ? (int)mat->slice.npanels : 1;
+  if (width) *width = mat->use_sweep ? (int)mat->sweep_width : mat->use_slice ? (int)mat->slice_width
+                                     : (int)(mat->fmt == ABFT_FMT_CSR ? mat->csr.n_in : mat->coo.n_in);
   return ABFT_OK;
 }
 

@@ -66,6 +66,36 @@ struct SweepLayout {
   uint32_t *debug;         // optional (ABFT_HIP_SWEEP_DEBUG): {polls that waited, waits, workgroup exits}, never reset
 };
 
+// Slice layout (round 3): the sweep layout's successor for scattered CSR matrices.  What the sweep
+// kernel paid per (row, panel) CELL -- a count byte, a share of a prefix scan, a range test, a branch,
+// and a workgroup barrier per tile -- was as much as it paid per element (config 4: 26 panels x 16 rows
+// = 416 cells for 400 elements per thread).  Here nothing is per cell:
+//   * rows are cut into SLICES of 2^rows_log2 consecutive rows; a slice belongs to ONE WAVE, which
+//     keeps the slice's running row sums in its own piece of LDS -- no other wave ever touches them,
+//     so the kernel has no barrier and no atomics at all;
+//   * a slice's elements are stored as one run ordered by (panel of the gather index, row, caller's
+//     order), each with its row inside the slice as a 16-bit id: the wave streams the run 64 elements
+//     per instruction -- chunks run straight across panel boundaries, every chunk but a slice's last
+//     is full -- and each element is added onto its row's sum in LDS, in storage order (the lanes
+//     of one chunk that share a row are folded in lane order by the first of them, over DPP);
+//     a row's elements therefore meet its sum in the caller's order (panels ascend; inside a panel a
+//     row's elements keep their order): y stays bit-identical to the reference;
+//   * `sub` (first element of every (slice, panel)) is only read for panel ranges and pacing.
+struct SliceLayout {
+  const uint32_t *sub;   // nslices * (npanels + 1): first stored element of (slice, panel); [.. + npanels] = the slice's end
+  const uint16_t *rid;   // per stored element: row - (slice << rows_log2) + 1 (0: no element -- a load past the end)
+  uint32_t nslices, npanels, rows_log2;
+  uint32_t *pace;        // a progress board per XCD (as SweepLayout::pace)
+  uint32_t lag;          // 0: no pacing
+};
+
+#ifndef ABFT_CFG_SLICE_K
+#define ABFT_CFG_SLICE_K 2  // chunks of 64 elements a wave of the slice kernel keeps in flight
+#endif
+#ifndef ABFT_CFG_SLICE_WAVES
+#define ABFT_CFG_SLICE_WAVES 8  // waves per SIMD the slice kernel is compiled for (register budget)
+#endif
+
 #ifndef ABFT_CFG_PANEL_RPT
 #define ABFT_CFG_PANEL_RPT 8  // outputs per thread of the panel kernels (4: equal on config 4, -14% on config 5)
 #endif
@@ -238,6 +268,10 @@ struct TileSpan {
 hipError_t launch_spmv_sweep(int mode, int rpt, const CsrDev &A, const SweepLayout &L, const double *x, double *y,
                              EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s);
 int spmv_sweep_blocks_per_cu(int mode, int rpt);  // rpt: 2, 4, 8 or 16
+// slice-layout SpMV (modes other than constraints): panels [c0, c1), `grid` workgroups of 4 waves
+hipError_t launch_spmv_slice(int mode, const CsrDev &A, const SliceLayout &L, const double *x, double *y, EventRing ev,
+                             const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s);
+int spmv_slice_blocks_per_cu(int mode, uint32_t rows_log2);
 
 // panel-layout SpMV (modes other than constraints); `grid` = resident workgroups
 hipError_t launch_spmv_csr_panels(int mode, const CsrDev &A, const CsrPanels &P, const double *x, double *y,

@@ -1479,6 +1479,342 @@ int spmv_sweep_blocks_per_cu(int mode, int rpt) {
   return n;
 }
 
+// ------------------------------------------------------------ slice-layout SpMV --
+
+// A wave-uniform word through the scalar cache.  hipcc only emits s_load for memory it can prove
+// nobody writes during the kernel; for a table reached through a struct member it falls back to a
+// vector load, whose s_waitcnt vmcnt(0) would drain every streaming load and gather in flight.
+__device__ __forceinline__ uint32_t scalar_load_u32(const uint32_t *p) {
+  uint32_t v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
+}
+
+// DPP moves across the whole wave (GFX9: wave_shr:1 / wave_shl:1); a lane without a source keeps `old`
+__device__ __forceinline__ uint32_t wave_shr1_u32(uint32_t v, uint32_t old) {  // lane i <- lane i - 1
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_shl1_u32(uint32_t v, uint32_t old) {  // lane i <- lane i + 1
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ double wave_shl1_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+// One chunk of 64 stored elements (one per lane, in storage order) added onto the wave's row
+// sums in LDS: lane i holds the product `p` of an element of local row r - 1 (r == 0: no element).
+// Inside one panel's part of a slice rows ascend, so the elements of one row are a run of lanes; the
+// run's first lane reads the row's sum, adds its own product and then its followers' in lane order
+// (the first follower unconditionally -- most chunks hold a pair -- longer runs in a loop of one DPP
+// shift per step) and writes the sum back.  A row that goes on in the next chunk is picked up there
+// by its first lane: the wave's LDS operations execute in order.  RANGED: only lanes [lo, hi) -- the
+// caller never folds elements of two panels at once: the same row may come again behind a panel
+// boundary, and two runs of one row in one call would both start from the old sum.
+// `accm1` = the wave's sums - 1 (so that r indexes it directly).
+template <bool RANGED>
+__device__ __forceinline__ void slice_fold(double *accm1, uint32_t r, double p, uint32_t lo = 0u, uint32_t hi = 64u) {
+  if (RANGED) {
+    const uint32_t lane = threadIdx.x & 63u;
+    r = (lane >= lo && lane < hi) ? r : 0u;
+  }
+  const uint32_t prev = wave_shr1_u32(r, 0u);
+  const bool head = r != 0u && r != prev;
+  double a = 0.0;
+  if (head) a = accm1[r];
+  a += p;
+  uint32_t rq = wave_shl1_u32(r, 0u);  // row and product of lane i + 1
+  double q = wave_shl1_f64(p);
+  bool still = head && rq == r;
+  if (still) a += q;
+  rq = wave_shl1_u32(rq, 0u);
+  still = still && rq == r;
+  while (__builtin_amdgcn_ballot_w64(still) != 0ull) {  // runs of three and more: rare
+    q = wave_shl1_f64(wave_shl1_f64(p));  // (recomputed here, off the common path)
+    uint32_t rr = rq;
+    for (;;) {
+      if (still) a += q;
+      rr = wave_shl1_u32(rr, 0u);
+      q = wave_shl1_f64(q);
+      still = still && rr == r;
+      if (__builtin_amdgcn_ballot_w64(still) == 0ull) break;
+    }
+  }
+  if (head) accm1[r] = a;
+}
+
+// Slice-layout SpMV (CSR; see SliceLayout): every wave owns slices s, s + (waves of the grid), ...
+// and streams each slice's run of elements K chunks of 64 at a time -- streaming loads of value,
+// column and row id, ECC in registers (cold path out of line, as everywhere), gather, multiply,
+// ordered fold into the wave's own row sums in LDS.  No barrier inside the sweep, no atomics, no
+// per-(row, panel) bookkeeping.  Reference order of additions: CSR/CPUContext.cpp:115-133 and the
+// ABFT variants.
+//
+// What bounds this kernel is the number of instructions issued per element (the first version spent
+// 150 vector and 80 scalar instructions per chunk and ran at 80 % issue occupancy), so:
+//   * every load is a buffer load: the address is base (SGPRs) + a 32-bit byte offset, and an offset
+//     past the end returns 0 -- no 64-bit address arithmetic, no clamping, no validity flags: a lane
+//     past the slice's end loads row id 0 = "no element", a column outside the gathered vector
+//     gathers 0.0 (the documented behaviour);
+//   * the chunks of one step share their offset registers (instruction offsets k * 512 / 256 / 128).
+// A wave is on its own here (no sibling fills its memory waits by construction of a tile), so the
+// loop is software-pipelined three deep: while the products of step i are folded, the gathers of
+// step i + 1 and the streaming loads of step i + 2 are in flight.  Branch-free: steps past the
+// slice's end load zeros and fold nothing.
+//
+// Pacing (speed only, as in the sweep kernel: the per-XCD progress board, plain stores, one
+// L1-bypassing load of the board per panel, every wait bounded).  The unit that publishes is the
+// workgroup: every wave notes the panel its gathers have reached in LDS, wave 0 -- when its own
+// changes, every few steps, in its own waits and, once its slices are done, until the other three are
+// done too -- stores the minimum of the four on the board when it has changed (one writer per slot:
+// monotone).  A wave whose gathers enter panel step t first needs every workgroup of its XCD to have
+// completed t - lag steps: the waves of an XCD gather from at most lag + 1 consecutive panels.
+template <int K> struct SliceLoads { u32x2 v[K]; uint32_t c[K], r[K]; };
+template <int K> struct SliceProds { double v[K], xv[K]; uint32_t r[K]; };
+
+constexpr int BUF_NT = 2;                  // aux of a buffer load: non-temporal
+constexpr uint32_t BUF_WORD3 = 0x00020000u;  // untyped 32-bit data, no swizzle, no add-tid
+
+// streaming loads of the step at `pos` (element index inside the slice, this lane's, chunk 0)
+template <int K>
+__device__ __forceinline__ void slice_issue_loads(__amdgpu_buffer_rsrc_t bv, __amdgpu_buffer_rsrc_t bc,
+                                                  __amdgpu_buffer_rsrc_t br, uint32_t pos, SliceLoads<K> &t) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    t.v[k] = __builtin_amdgcn_raw_buffer_load_b64(bv, (pos << 3) + 512 * k, 0, BUF_NT);
+    t.c[k] = __builtin_amdgcn_raw_buffer_load_b32(bc, (pos << 2) + 256 * k, 0, BUF_NT);
+    t.r[k] = __builtin_amdgcn_raw_buffer_load_b16(br, (pos << 1) + 128 * k, 0, BUF_NT);
+  }
+}
+
+// ECC check of the loaded elements of a step, their gathers issued; products are formed at the fold.
+// `first` = stored position of this lane's chunk-0 element (cold path only).
+template <int MODE, int K>
+__device__ __forceinline__ void slice_consume(const CsrDev &A, __amdgpu_buffer_rsrc_t bx, const EventRing &ev,
+                                              uint32_t first, const SliceLoads<K> &t, SliceProds<K> &o) {
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    uint32_t w[3] = {t.v[k].x, t.v[k].y, t.c[k]};
+    bool fatal = false;
+    if (MODE >= MODE_SED) {
+      // (a lane past the slice's end holds three zero words: a clean codeword in every mode)
+      if (__builtin_expect(ecc_suspect<FMT_CSR, MODE>(w) != 0, 0)) {
+        const uint32_t i = first + 64u * (uint32_t)k;
+        EccWords<FMT_CSR> ew;
+        ew.w[0] = w[0]; ew.w[1] = w[1]; ew.w[2] = w[2]; ew.rc = 0;
+        ew = ecc_cold<FMT_CSR, MODE>(ew, event_index(A, i), ev);
+        w[0] = ew.w[0]; w[1] = ew.w[1]; w[2] = ew.w[2];
+        if (ew.rc > 0) {  // reference CSR/CPUContext.cpp:275-276, 333-334, 389-390
+          A.vals[i] = as_double(w[0], w[1]);
+          A.cols[i] = w[2];
+        } else {
+          fatal = true;  // the reference never uses this element
+        }
+      }
+      w[2] &= ABFT_COLMASK;
+    }
+    // the gather: an index outside the vector reads 0.0 (bounds-checked by the buffer); 2^29 and more
+    // would wrap the byte offset, so they are pinned to one that is out of range for any vector
+#ifdef ABFT_DBG_NOGATHER  // timing-only build: wrong results
+    o.xv[k] = (double)w[2];
+#else
+    const u32x2 g = __builtin_amdgcn_raw_buffer_load_b64(bx, min(w[2], 0x1fffffffu) << 3, 0, 0);
+    o.xv[k] = as_double(g.x, g.y);
+#endif
+    // (no use of xv here: the gather stays in flight until the fold)
+    o.v[k] = fatal ? 0.0 : as_double(w[0], w[1]);
+    o.r[k] = t.r[k];
+  }
+}
+
+template <int MODE, int K>
+__global__ __launch_bounds__(ABFT_BLOCK, ABFT_CFG_SLICE_WAVES) void spmv_slice_kernel(
+    CsrDev A, SliceLayout L, const double *__restrict__ x, double *__restrict__ y, EventRing ev, FuseOut fuse,
+    bool fused, uint32_t c0, uint32_t c1) {
+  extern __shared__ __attribute__((aligned(16))) double s_rows[];  // 4 waves x 2^rows_log2 row sums
+  __shared__ uint32_t s_prog[4];  // panel steps each wave has completed
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t R = 1u << L.rows_log2;
+  double *acc = s_rows + (size_t)wave * R;
+  const uint32_t nwaves = gridDim.x * 4u, nsteps = c1 - c0;
+  const uint32_t nrounds = (L.nslices + nwaves - 1u) / nwaves;
+  const uint32_t slot = blockIdx.x >> 3;  // workgroups are dealt to the XCDs round-robin: distinct slots per board
+  const bool pace = L.lag != 0u && slot < PACE_SLOTS;
+  uint32_t *board = pace ? L.pace + xcc_id() * PACE_SLOTS : nullptr;
+  uint32_t last_pub = 0u, last_done = 0u, since_pub = 0u;
+  BoardView seen{~0ull, ~0ull};
+  bool have_seen = false, gave_up = false;
+  if (pace) {
+    if (lane == 0u) s_prog[wave] = 0u;
+    if (threadIdx.x == 0u) board[slot] = 0u;
+    __syncthreads();
+  }
+  // wave 0: the workgroup's progress = the slowest of its four waves, stored when it has changed
+  auto publish = [&]() {
+    // (atomic: re-read every time, never cached in a register across the loops below)
+    const uint32_t m = min(min(__hip_atomic_load(&s_prog[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                               __hip_atomic_load(&s_prog[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                           min(__hip_atomic_load(&s_prog[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                               __hip_atomic_load(&s_prog[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+    if (m != last_pub) {
+      last_pub = m;
+      if (lane == 0u) board[slot] = m;  // plain store: into this XCD's L2
+    }
+    since_pub = 0u;
+    return m;
+  };
+  constexpr uint32_t STEP = 64u * K;
+  const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x), 0, (int)(A.n_in * 8u), BUF_WORD3);
+  double dsum = 0.0;
+  for (uint32_t round = 0; round < nrounds; round++) {
+    const uint32_t s = round * nwaves + blockIdx.x * 4u + wave;
+    if (s >= L.nslices) break;  // (uniform per wave; the tail below reports this wave as done)
+    const uint32_t row0 = s << L.rows_log2;
+    for (uint32_t i = lane; i < R; i += 64u) {
+      const uint32_t row = row0 + i;
+      acc[i] = (c0 > 0u && row < A.n_out) ? y[row] : 0.0;  // a later panel range resumes from y (exact)
+    }
+    const uint32_t *sb = L.sub + (size_t)s * (L.npanels + 1u);
+    const uint32_t e0 = scalar_load_u32(sb + c0), e1 = scalar_load_u32(sb + c1);  // wave-uniform
+    const uint32_t len = e1 - e0;
+    // this slice's run of each array as a buffer: offsets count from e0, anything past e1 reads 0
+    const __amdgpu_buffer_rsrc_t bv = __builtin_amdgcn_make_buffer_rsrc(A.vals + e0, 0, (int)(len * 8u), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t bc = __builtin_amdgcn_make_buffer_rsrc(A.cols + e0, 0, (int)(len * 4u), BUF_WORD3);
+    const __amdgpu_buffer_rsrc_t br =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(L.rid) + e0, 0, (int)(len * 2u), BUF_WORD3);
+    uint32_t pc = c0, pend = scalar_load_u32(sb + c0 + 1u) - e0;  // gather cursor: panel `pc` ends at slice position pend
+    uint32_t cur = c0, nb = pend;                                   // fold cursor, one step behind
+    // before the gathers of step [e, e + STEP) go out: progress, and the pacing check when they enter a new panel
+    auto pace_step = [&](uint32_t e) {
+      const uint32_t done = round * nsteps + (pc - c0);  // every panel before the previous step's last is behind this wave
+      const uint32_t last = min(e + STEP, len) - 1u;
+      bool entered = false;
+      while (pend <= last && pc + 1u < c1) { pc++; pend = scalar_load_u32(sb + pc + 1u) - e0; entered = true; }
+      if (done != last_done) {
+        last_done = done;
+        if (lane == 0u) __hip_atomic_store(&s_prog[wave], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        since_pub = 8u;
+      }
+      if (wave == 0u && ++since_pub >= 8u) publish();
+      if (entered && !gave_up) {
+        const uint32_t step = round * nsteps + (pc - c0);
+        if (step > L.lag) {
+          // (the step that enters panel `step` also ends panel step - 1, so this wave itself has
+          // completed `done` < step steps: it never waits for more than that)
+          const uint32_t need = min(step - L.lag, done);
+          uint32_t m = have_seen ? board_min(seen) : 0u;
+          if (m < need) {
+            int it = 0;
+            for (; it < 1024 && m < need; it++) {
+              __builtin_amdgcn_s_sleep(4);
+              if (wave == 0u) publish();
+              m = board_min(board_load(board, lane));
+            }
+            if (it == 1024) gave_up = true;  // ~1 ms: a workgroup of this XCD is not running -- stop pacing
+          }
+        }
+        seen = board_load(board, lane);  // for the next panel: its latency runs beside this panel's work
+        have_seen = true;
+      }
+    };
+    SliceLoads<K> ld;
+    SliceProds<K> p0, p1;
+    double *accm1 = acc - 1;
+    if (len) {
+      slice_issue_loads<K>(bv, bc, br, lane, ld);
+      if (pace) pace_step(0u);
+      slice_consume<MODE, K>(A, bx, ev, e0 + lane, ld, p0);
+      slice_issue_loads<K>(bv, bc, br, STEP + lane, ld);
+    }
+    for (uint32_t e = 0; e < len; e += STEP) {  // e: position inside the slice
+      // in flight here: the gathers of step e (p0), the streaming loads of step e + STEP (ld)
+      if (pace && e + STEP < len) pace_step(e + STEP);
+      slice_consume<MODE, K>(A, bx, ev, e0 + e + STEP + lane, ld, p1);  // (past the end: zeros, nothing to fold)
+      slice_issue_loads<K>(bv, bc, br, e + 2u * STEP + lane, ld);
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const uint32_t b = e + 64u * (uint32_t)k;  // slice position of lane 0's element
+        const double p = p0.v[k] * p0.xv[k];
+        if (nb >= b + 64u || cur + 1u >= c1) {  // (uniform) the whole chunk lies in one panel: nearly always
+          slice_fold<false>(accm1, p0.r[k], p);
+        } else {
+          // one fold per panel the chunk holds elements of
+          for (uint32_t lo = 0u; b + lo < len;) {
+            while (nb <= b + lo && cur + 1u < c1) { cur++; nb = scalar_load_u32(sb + cur + 1u) - e0; }
+            const uint32_t hi = nb - b < 64u ? nb - b : 64u;
+            slice_fold<true>(accm1, p0.r[k], p, lo, hi);
+            if (hi >= 64u) break;
+            lo = hi;
+          }
+        }
+      }
+      p0 = p1;
+    }
+    for (uint32_t i = lane; i < R; i += 64u) {
+      const uint32_t row = row0 + i;
+      if (row < A.n_out) {
+        const double a = acc[i];
+        y[row] = a;
+        if (fused) dsum += x[fuse.x_off + row] * a;
+      }
+    }
+  }
+  if (pace) {
+    // this wave is done with every round; wave 0 goes on publishing until its three neighbours are too,
+    // then leaves the slot at "nobody here" (clean for the next launch, and never holding anyone back)
+    if (lane == 0u) __hip_atomic_store(&s_prog[wave], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wave == 0u) {
+      for (int it = 0; it < (1 << 20) && publish() != 0xffffffffu; it++) __builtin_amdgcn_s_sleep(8);
+      if (lane == 0u) board[slot] = 0xffffffffu;
+    }
+  }
+  if (fused) fused_dot_finish(dsum, fuse, blockIdx.x);
+}
+
+template <int MODE>
+static hipError_t launch_slice_inst(const CsrDev &A, const SliceLayout &L, const double *x, double *y, EventRing ev,
+                                    const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+  const size_t lds = (size_t)4 * sizeof(double) << L.rows_log2;
+  hipLaunchKernelGGL((spmv_slice_kernel<MODE, ABFT_CFG_SLICE_K>), dim3(grid), dim3(ABFT_BLOCK), lds, s, A, L, x, y, ev,
+                     fuse ? *fuse : FuseOut{}, fuse != nullptr, c0, c1);
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_slice(int mode, const CsrDev &A, const SliceLayout &L, const double *x, double *y, EventRing ev,
+                             const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+  if (L.nslices == 0 || c0 >= c1) return hipSuccess;
+  if (c1 > L.npanels || grid == 0 || L.rows_log2 > 11u) return hipErrorInvalidValue;
+  switch (mode) {
+    case MODE_NONE: return launch_slice_inst<MODE_NONE>(A, L, x, y, ev, fuse, grid, c0, c1, s);
+    case MODE_SED: return launch_slice_inst<MODE_SED>(A, L, x, y, ev, fuse, grid, c0, c1, s);
+    case MODE_SEC7: return launch_slice_inst<MODE_SEC7>(A, L, x, y, ev, fuse, grid, c0, c1, s);
+    case MODE_SEC8: return launch_slice_inst<MODE_SEC8>(A, L, x, y, ev, fuse, grid, c0, c1, s);
+    case MODE_SECDED: return launch_slice_inst<MODE_SECDED>(A, L, x, y, ev, fuse, grid, c0, c1, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int MODE> static int slice_occupancy_inst(size_t lds) {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_slice_kernel<MODE, ABFT_CFG_SLICE_K>, ABFT_BLOCK, lds) !=
+          hipSuccess || n < 1)
+    n = 1;
+  return n > 8 ? 8 : n;
+}
+
+int spmv_slice_blocks_per_cu(int mode, uint32_t rows_log2) {
+  const size_t lds = (size_t)4 * sizeof(double) << rows_log2;
+  switch (mode) {
+    case MODE_NONE: return slice_occupancy_inst<MODE_NONE>(lds);
+    case MODE_SED: return slice_occupancy_inst<MODE_SED>(lds);
+    case MODE_SEC7: return slice_occupancy_inst<MODE_SEC7>(lds);
+    case MODE_SEC8: return slice_occupancy_inst<MODE_SEC8>(lds);
+    default: return slice_occupancy_inst<MODE_SECDED>(lds);
+  }
+}
+
 // ------------------------------------------------- COO: corrupted-column fix-up --
 
 // Launched behind every COO SpMV (one workgroup; returns at once when the SpMV queued

@@ -541,6 +541,49 @@ def test_sweep_layout_forced_on_small_matrices(amd, fmt, width, rpt, lag, monkey
                 h.close()
 
 
+@pytest.mark.parametrize("width,srows,lag", [(16, 64, 2), (16, 16, 0), (257, 128, 1), (100000, 1024, 3), (64, 32, 2)])
+def test_slice_layout_forced_on_small_matrices(amd, width, srows, lag, monkeypatch):
+    """The slice layout (CSR: a wave owns a slice of rows, keeps their running sums in its own piece of
+    LDS and streams the slice's elements, ordered by (panel, row), 64 per instruction; the lanes of a
+    chunk that share a row are folded in lane order over DPP) is normally chosen only for large
+    scattered matrices (full size: test_gpu_fullsize); force it here with tiny panels and every slice
+    size through the same checks as the streaming layout: stored elements in the caller's order, SpMV
+    bit-identical (rows longer than a chunk, empty rows, rows that continue in the next chunk), flips
+    reported with the caller's index and repaired, fused dot, panel ranges."""
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "slice")
+    monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", str(width))
+    monkeypatch.setenv("ABFT_HIP_SLICE_ROWS", str(srows))
+    monkeypatch.setenv("ABFT_HIP_SLICE_LAG", str(lag))
+    for mat in ("ragged", "rnd300", "lap40", "one", "tail_empty", "empty"):
+        cols, rows, vals, n = MATS[mat]()
+        x = rhs(n, 11) - 0.5
+        for mode in ("none", "sed", "sec7", "sec8", "secded"):
+            o = OracleMatrix(CSR, mode, cols, rows, vals, n)
+            h = Hip(amd, CSR, mode, cols, rows, vals, n)
+            try:
+                layout = h.ctx.matrix_info(h.A)[0]
+                assert layout == ("slice" if len(vals) else "stream"), (mat, layout)
+                assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+                assert bits_equal(h.spmv(x), o.spmv(x))
+                assert h.take_events() == ([], False)
+                if mode not in ("none", "sed") and len(vals) > 2:
+                    idx = [0, len(vals) // 2, len(vals) - 1]
+                    for k, i in enumerate(idx):
+                        o.inject(i, [7 + 30 * k])
+                        h.ctx.inject_at(h.A, i, [7 + 30 * k])
+                    assert bits_equal(h.spmv(x), o.spmv(x))
+                    assert h.take_events() == o.events()
+                    assert np.array_equal(h.ctx.stored_words(h.A), o.stored_words())
+                for _ in range(2):  # again, with the fused dot
+                    h.ctx.spmv(h.A, h.vx, h.vy)
+                    d = h.ctx.dot(h.vx, h.vy)
+                    y = h.ctx.download(h.vy)
+                    assert bits_equal(y, o.spmv(x))
+                    assert abs(d - ora_dot(x, y)) <= 1e-13 * float(np.abs(x * y).sum()) + 1e-300
+            finally:
+                h.close()
+
+
 @pytest.mark.parametrize("fmt", FMTS)
 @pytest.mark.parametrize("width,chunk", [(16, 0), (16, 3), (257, 1), (100000, 2)])
 def test_panel_layout_forced_on_small_matrices(amd, fmt, width, chunk, monkeypatch):
@@ -636,14 +679,15 @@ def test_coo_silently_corrupted_column_scatters_like_reference(amd, mode, layout
     assert compared >= 6 and moved >= 5, (compared, moved)
 
 
+@pytest.mark.parametrize("layout", ["sweep", "slice"])
 @pytest.mark.parametrize("mode", ["none", "secded"])
-def test_spmv_by_panel_ranges_equals_one_launch(amd, mode, monkeypatch):
+def test_spmv_by_panel_ranges_equals_one_launch(amd, mode, layout, monkeypatch):
     """abft_hip_spmv_dot_range_dev: the panel sweep cut into ranges (a shard whose input vector
     arrives slot by slot) -- the ranges in ascending order equal one launch bit for bit, y and
     the fused product; the second range only reads its own part of the input vector."""
     import ctypes as C
     from abft_sparse_cg_amd import capi
-    monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep")
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", layout)
     monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", "64")
     cols, rows, vals, n = MATS["rnd300"]()
     x = rhs(n, 4)

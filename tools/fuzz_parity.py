@@ -66,7 +66,9 @@ def one_case(seed):
     nnz = len(vals)
     fmt = CSR if rng.random() < 0.6 else COO
     mode = str(rng.choice(MODES))
-    layout = str(rng.choice(["stream", "panels", "sweep", "sweep", "auto"]))
+    layout = str(rng.choice(["stream", "panels", "sweep", "slice", "slice", "auto"]))
+    os.environ["ABFT_HIP_SLICE_ROWS"] = str(int(rng.choice([16, 64, 256, 1024])))
+    os.environ["ABFT_HIP_SLICE_LAG"] = str(int(rng.choice([0, 1, 2, 3])))
     os.environ["ABFT_HIP_SWEEP_RPT"] = str(int(rng.choice([8, 16])))
     os.environ["ABFT_HIP_SWEEP_LAG"] = str(int(rng.choice([0, 1, 2, 3])))
     os.environ["ABFT_HIP_LAYOUT"] = layout
