@@ -207,7 +207,7 @@ def load_matrix(o, row0=0, row1=None):
 
 def run_single(o):
     from . import HIPContext, generators
-    from .context import fdiv
+    from .context import fdiv, note_threshold
     cols, rows, vals, n, block = load_matrix(o)
     nnz = len(vals)
     ctx = HIPContext(o["mode"], o["fmt"])
@@ -227,6 +227,8 @@ def run_single(o):
     ctx.copy_vector(p, r)
     rr = ctx.dot(r, r)
     itr = 0
+    noted = {}
+    note_threshold(rr, o["conv"], noted)
     while itr < o["max_itrs"] and rr > o["conv"]:
         ctx.spmv(A, p, w)
         pw = ctx.dot(p, w)
@@ -234,6 +236,7 @@ def run_single(o):
         rr_new = ctx.calc_xr(x, r, p, w, alpha)
         ctx.calc_p(p, r, fdiv(rr_new, rr))
         rr = rr_new
+        note_threshold(rr, o["conv"], noted)
         if not o["quiet"]:
             print("iteration %5u :  rr = %12.4f" % (itr, rr))
         itr += 1

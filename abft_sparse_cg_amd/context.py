@@ -307,12 +307,31 @@ def fdiv(a, b):
     return a / b
 
 
+def threshold_ambiguous(rr, conv_threshold):
+    """True when rr lies within rounding of the stop test's threshold (reference cg.cpp:94): the two
+    reductions are tree sums, ~1e-13 relative from the reference's serial sums, so only then can the
+    iteration count differ from the reference's by one ("iteration-count parity")."""
+    return conv_threshold > 0.0 and abs(rr - conv_threshold) <= 1e-12 * abs(rr)
+
+
+def note_threshold(rr, conv_threshold, state):
+    """one stderr line per run when the stop test is ambiguous (stdout stays the reference's)"""
+    import sys
+    if not state.get("noted") and threshold_ambiguous(rr, conv_threshold):
+        state["noted"] = True
+        sys.stderr.write("note: threshold-ambiguous run: rr = %s is within 1e-12 (relative) of the convergence "
+                         "threshold %.17g; the reference's serially summed rr may fall on the other side and run "
+                         "one iteration more or fewer\n" % (float(rr).hex(), conv_threshold))
+
+
 def cg_solve(ctx, A, b, x, r, p, w, max_itrs=1000, conv_threshold=1e-3, on_iteration=None):
     """The reference driver's CG loop, call for call (cg.cpp:87-118)."""
     ctx.copy_vector(r, b)
     ctx.copy_vector(p, r)
     rr = ctx.dot(r, r)
     itr = 0
+    noted = {}
+    note_threshold(rr, conv_threshold, noted)
     while itr < max_itrs and rr > conv_threshold:
         ctx.spmv(A, p, w)
         pw = ctx.dot(p, w)
@@ -321,6 +340,7 @@ def cg_solve(ctx, A, b, x, r, p, w, max_itrs=1000, conv_threshold=1e-3, on_itera
         beta = fdiv(rr_new, rr)
         ctx.calc_p(p, r, beta)
         rr = rr_new
+        note_threshold(rr, conv_threshold, noted)
         if on_iteration is not None:
             on_iteration(itr, rr)
         itr += 1

@@ -380,6 +380,23 @@ int main(int argc, char *argv[])
   // ABFT_CG_HEX=1: every rr also goes to stderr with all its bits (tests hold the residual
   // history to 1e-10; the report line below keeps the reference's four decimals)
   const bool hex_trace = getenv("ABFT_CG_HEX") != NULL;
+  // The two reductions are tree sums: they agree with the reference's serial sums to ~1e-13 relative
+  // ("iteration-count parity"), so the stop test `rr > threshold` (reference cg.cpp:94) can
+  // only come out differently when rr lands within rounding of the threshold.  Say so when it does --
+  // one line on stderr (stdout stays the reference's), rank 0 only -- instead of leaving it to chance.
+  CGContextExt *ext_note = dynamic_cast<CGContextExt *>(context);
+  const bool note_rank = !ext_note || ext_note->ext_rank() == 0;
+  bool noted = false;
+  auto threshold_note = [&](double v, int at)
+  {
+    if (noted || !note_rank || !(o.conv_threshold > 0.0) || !(fabs(v - o.conv_threshold) <= 1e-12 * fabs(v)))
+      return;
+    noted = true;
+    fprintf(stderr, "note: threshold-ambiguous run: rr = %a %s is within 1e-12 (relative) of the convergence "
+            "threshold %.17g; the reference's serially summed rr may fall on the other side and run one iteration "
+            "more or fewer\n", v, at < 0 ? "before the first iteration" : "after an iteration", o.conv_threshold);
+  };
+  threshold_note(rr, -1);
   int itr = 0;
   for (; itr < o.max_itrs && rr > o.conv_threshold; itr++)
   {
@@ -394,6 +411,7 @@ int main(int argc, char *argv[])
       printf("iteration %5u :  rr = %12.4lf\n", itr, rr);
     if (hex_trace)
       fprintf(stderr, "rr %d %a\n", itr, rr);
+    threshold_note(rr, itr);
   }
 
   double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -35,22 +35,66 @@ static int env_int(const char *name, int fallback)
 // anything has touched a GPU (plain fork: every rank then runs the unchanged driver from where
 // the backend was created; SURVEY 5 names the variable).  Returns the children's pids.
 static std::vector<int> g_children;
+static int g_listen_fd = -1;  // self-launch: rank 0's rendezvous socket, bound before the fork and kept
+
+// wait for the ranks this process started; -> the first non-zero exit status among them (128 + signal)
+static int reap_children()
+{
+  int worst = 0;
+  for (size_t i = 0; i < g_children.size(); i++)
+  {
+    int status = 0;
+    if (waitpid((pid_t)g_children[i], &status, 0) < 0) continue;
+    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : WIFSIGNALED(status) ? 128 + WTERMSIG(status) : 1;
+    if (code && !worst) worst = code;
+  }
+  g_children.clear();
+  return worst;
+}
+
+// Runs on every exit() of the rank that self-launched the others (the driver's normal return, fail(),
+// the fatal-ECC exit(1), check()): the children are always reaped, and a rank that crashed or exited
+// non-zero is not hidden behind a parent that returns 0.
+static void reap_at_exit(int status, void *)
+{
+  const int worst = reap_children();
+  if (status == 0 && worst != 0)
+  {
+    fprintf(stderr, "hip backend (comm): a rank started by ABFT_HIP_GPUS ended with status %d\n", worst);
+    fflush(NULL);
+    _exit(worst);
+  }
+}
 
 static void self_launch(int n)
 {
-  // a free port for the rendezvous: ask the kernel for one, then let it go again
-  int port = 29400;
-  int probe = socket(AF_INET, SOCK_STREAM, 0);
-  if (probe >= 0)
+  // fork() is only safe while nothing has initialised the GPU runtime.  Under rocprofv3 the preloaded
+  // tool library has done so before main(): the forked ranks would inherit an unusable runtime.
+  const char *preload = getenv("LD_PRELOAD");
+  if (getenv("ROCP_TOOL_LIBRARIES") || (preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer"))))
   {
+    fprintf(stderr, "hip backend (comm): ABFT_HIP_GPUS cannot fork its ranks under a profiler's preloaded library "
+            "(the GPU runtime is already initialised); start the ranks with a launcher instead: "
+            "host/mgpu-run N -- rocprofv3 ... -- cg-csr ...\n");
+    exit(2);
+  }
+  // the rendezvous socket: bound once here, on a port the kernel picks, and kept by rank 0 (nothing
+  // is probed and released again for another process to grab)
+  int port = 29400;
+  g_listen_fd = socket(AF_INET, SOCK_STREAM, 0);
+  if (g_listen_fd < 0) die("socket");
+  {
+    const int one = 1;
+    setsockopt(g_listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
     sockaddr_in sa;
     memset(&sa, 0, sizeof(sa));
     sa.sin_family = AF_INET;
     sa.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
     socklen_t len = sizeof(sa);
-    if (bind(probe, (sockaddr *)&sa, sizeof(sa)) == 0 && getsockname(probe, (sockaddr *)&sa, &len) == 0)
-      port = ntohs(sa.sin_port);
-    close(probe);
+    if (bind(g_listen_fd, (sockaddr *)&sa, sizeof(sa)) < 0 || getsockname(g_listen_fd, (sockaddr *)&sa, &len) < 0 ||
+        listen(g_listen_fd, n) < 0)
+      die("bind/listen (self-launch rendezvous)");
+    port = ntohs(sa.sin_port);
   }
   char buf[32];
   setenv("MASTER_ADDR", "127.0.0.1", 1);
@@ -72,10 +116,13 @@ static void self_launch(int n)
       setenv("RANK", buf, 1);
       setenv("LOCAL_RANK", buf, 1);
       g_children.clear();
+      close(g_listen_fd);  // rank 0's
+      g_listen_fd = -1;
       return;
     }
     g_children.push_back((int)pid);
   }
+  on_exit(reap_at_exit, NULL);
 }
 
 Comm* Comm::from_env()
@@ -116,13 +163,10 @@ Comm::~Comm()
       close(peers_[i]);
   if (listen_fd_ >= 0)
     close(listen_fd_);
-  for (size_t i = 0; i < g_children.size(); i++)  // ABFT_HIP_GPUS: the ranks this process started
-  {
-    int status = 0;
-    waitpid((pid_t)g_children[i], &status, 0);
-  }
-  g_children.clear();
+  // (ABFT_HIP_GPUS: the ranks this process started are reaped, and their status kept, by reap_at_exit)
 }
+
+int Comm::rccl_comm_count(int *device) const { return abft_rccl_comm_count(rccl_, device); }
 
 void Comm::enable_device_collectives(int device)
 {
@@ -139,20 +183,28 @@ void Comm::connect_star(const char *addr, int port)
   const int one = 1;
   if (rank_ == 0)
   {
-    listen_fd_ = socket(AF_INET, SOCK_STREAM, 0);
-    if (listen_fd_ < 0) die("socket");
-    setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
-    sockaddr_in sa;
-    memset(&sa, 0, sizeof(sa));
-    sa.sin_family = AF_INET;
-    sa.sin_port = htons((uint16_t)port);
-    // one node: listen on the loopback address when that is what the ranks were given
-    in_addr local;
-    sa.sin_addr.s_addr = htonl(INADDR_ANY);
-    if (inet_pton(AF_INET, addr, &local) == 1 && (ntohl(local.s_addr) >> 24) == 127)
-      sa.sin_addr = local;
-    if (bind(listen_fd_, (sockaddr *)&sa, sizeof(sa)) < 0) die("bind (MASTER_PORT in use?)");
-    if (listen(listen_fd_, size_) < 0) die("listen");
+    if (g_listen_fd >= 0)
+    {
+      listen_fd_ = g_listen_fd;  // self-launch: already bound and listening
+      g_listen_fd = -1;
+    }
+    else
+    {
+      listen_fd_ = socket(AF_INET, SOCK_STREAM, 0);
+      if (listen_fd_ < 0) die("socket");
+      setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
+      sockaddr_in sa;
+      memset(&sa, 0, sizeof(sa));
+      sa.sin_family = AF_INET;
+      sa.sin_port = htons((uint16_t)port);
+      // one node: listen on the loopback address when that is what the ranks were given
+      in_addr local;
+      sa.sin_addr.s_addr = htonl(INADDR_ANY);
+      if (inet_pton(AF_INET, addr, &local) == 1 && (ntohl(local.s_addr) >> 24) == 127)
+        sa.sin_addr = local;
+      if (bind(listen_fd_, (sockaddr *)&sa, sizeof(sa)) < 0) die("bind (MASTER_PORT in use?)");
+      if (listen(listen_fd_, size_) < 0) die("listen");
+    }
     peers_.assign(size_, -1);
     // a peer that died before connecting (bad device, failed exec) must not leave rank 0
     // -- and the launcher waiting on it -- blocked for ever: one deadline for the rendezvous

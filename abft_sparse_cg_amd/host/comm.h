@@ -45,6 +45,7 @@ public:
   // call once the process has chosen its GPU; no-op when built without RCCL or ABFT_COMM=tcp
   void enable_device_collectives(int device);
   bool device_collectives() const { return rccl_ != NULL; }
+  int rccl_comm_count(int *device) const;  // ncclCommCount of the communicator (0: none) and its device
   // v[0..n) += over ranks, in place, device memory
   void allreduce_sum_device(double *dev, int n, void *stream);
   // Vector exchange: between begin and finish the two calls below run on `stream` itself, or
@@ -74,6 +75,7 @@ private:
 // comm_rccl.cpp (or its stub when built without RCCL)
 void* abft_rccl_init(Comm *host, int device);
 void  abft_rccl_destroy(void *comm);
+int   abft_rccl_comm_count(void *comm, int *device);  // ncclCommCount / ncclCommCuDevice (0: no communicator)
 void  abft_rccl_allreduce_sum(void *comm, double *dev, int n, void *stream);
 void  abft_rccl_exchange_begin(void *comm, void *stream, bool beside);
 void  abft_rccl_exchange_finish(void *comm, void *stream);

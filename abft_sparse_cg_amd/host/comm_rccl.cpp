@@ -71,6 +71,20 @@ void abft_rccl_destroy(void *p)
   delete st;
 }
 
+// ranks of the communicator as RCCL itself counts them (ncclCommCount), and the device it sits on
+int abft_rccl_comm_count(void *p, int *device)
+{
+  RcclState *st = (RcclState *)p;
+  int n = 0, dev = -1;
+  if (!st)
+    return 0;
+  check_nccl(ncclCommCount(st->comm, &n), "ncclCommCount");
+  check_nccl(ncclCommCuDevice(st->comm, &dev), "ncclCommCuDevice");
+  if (device)
+    *device = dev;
+  return n;
+}
+
 void abft_rccl_allreduce_sum(void *p, double *dev, int n, void *stream)
 {
   RcclState *st = (RcclState *)p;
@@ -121,6 +135,7 @@ void abft_rccl_sendrecv(void *p, const std::vector<Comm::Piece> &out, const std:
 
 void* abft_rccl_init(Comm *, int) { return NULL; }
 void  abft_rccl_destroy(void *) {}
+int   abft_rccl_comm_count(void *, int *) { return 0; }
 void  abft_rccl_allreduce_sum(void *, double *, int, void *) { abort(); }
 void  abft_rccl_exchange_begin(void *, void *, bool) { abort(); }
 void  abft_rccl_exchange_finish(void *, void *) { abort(); }

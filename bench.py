@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy peak reported beside it
+BLOCKS = 5              # N = 1: the K timed steps are repeated this many times; the median block is reported
+CPU_RUNS = 5            # CPU baseline: runs per figure (reference run_benchmark:3,19-25: mean (min / max))
 
 
 def parse():
@@ -38,8 +40,8 @@ def parse():
     ap.add_argument("--mode", default="none")
     ap.add_argument("--fmt", default="csr", choices=["csr", "coo"])
     ap.add_argument("--cpu-iters", type=int, default=160,
-                    help="CG iterations of the CPU baseline sample on all host cores, ~10 s (0 = skip); "
-                         "an eighth of that is also timed on one core")
+                    help="CG iterations of the CPU baseline sample on all host cores, in 5 runs (mean / min / max), "
+                         "~10 s (0 = skip); a quarter of that is also timed on one core")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket SpMV launches with HIP events")
     ap.add_argument("--profile-all", action="store_true",
                     help="bracket all four kernels, not only the SpMV (costs ~10%% of the iteration rate)")
@@ -167,14 +169,20 @@ def single(args):
         # or more often when the run is short, so that at least ~25 launches are averaged
         stride = 1 if args.profile_all else max(1, min(4, args.steps // 25))
         ctx.profile(0xF if args.profile_all else 1 << capi.K_SPMV, stride=stride)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # The timed region: exactly `steps` iterations between two synchronisations -- timed BLOCKS times back
+    # to back (a 5 ms window is shorter than this pool's run-to-run spread): `value` comes from the median
+    # block, the fastest and the slowest ride along as value_max / value_min.
+    block_dt = []
+    for _ in range(BLOCKS):
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        block_dt.append(time.perf_counter() - t0)
+    dt = sorted(block_dt)[len(block_dt) // 2]
 
     roof = None
     kernels = {}
@@ -230,57 +238,60 @@ def single(args):
     if args.cpu_iters > 0 and args.fmt == "csr":
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import baseline  # the CPU checker, timed as a baseline only
-        res = baseline.time_cg(cols, rows, vals, n, args.mode, args.cpu_iters)
-        one = baseline.time_cg(cols, rows, vals, n, args.mode, max(args.cpu_iters // 8, 2), threads=1)
-        cpu = {"value": round(res["it_per_s"], 3), "unit": "CG iterations/s", "cores": res["cores"],
-               "cpu_model": cpu_model(), "kind": res["kind"],
-               "sample": "%d CG iterations of the same matrix (%s, -m %s), OpenMP spmv + serial vector ops as the "
-                         "reference, %.1f s" % (res["iters"], args.spec, args.mode, res["seconds"]),
-               "one_core": {"value": round(one["it_per_s"], 3), "cores": 1,
-                            "sample": "%d iterations, %.1f s" % (one["iters"], one["seconds"])}}
+        # the reference's protocol (run_benchmark:3,19-25): NUM_RUNS = 5 runs, mean (min / max) -- here of
+        # CG iterations/s over 5 runs of cpu_iters / 5 iterations each, on all host cores and on one
+        per = max(args.cpu_iters // CPU_RUNS, 2)
+
+        def stats(res):
+            v = res["it_per_s_runs"]
+            return {"value": round(sum(v) / len(v), 3), "min": round(min(v), 3), "max": round(max(v), 3), "runs": len(v),
+                    "cores": res["cores"], "sample": "%d runs of %d CG iterations, %.1f s in all"
+                                                     % (len(v), res["iters"], res["seconds"])}
+
+        res = baseline.time_cg(cols, rows, vals, n, args.mode, per, runs=CPU_RUNS)
+        one = baseline.time_cg(cols, rows, vals, n, args.mode, max(per // 4, 2), threads=1, runs=CPU_RUNS)
+        cpu = stats(res)
+        cpu.update({"unit": "CG iterations/s", "cpu_model": cpu_model(), "kind": res["kind"],
+                    "sample": "mean (min / max) of %d runs of %d CG iterations each of the same matrix (%s, -m %s), "
+                              "OpenMP spmv + serial vector ops as the reference, %.1f s in all"
+                              % (CPU_RUNS, res["iters"], args.spec, args.mode, res["seconds"]),
+                    "one_core": stats(one)})
         if args.extras and args.mode != "secded":
-            sec = baseline.time_cg(cols, rows, vals, n, "secded", max(args.cpu_iters // 2, 2))
-            cpu["secded"] = {"value": round(sec["it_per_s"], 3), "cores": sec["cores"],
-                             "sample": "%d iterations of the same matrix with -m secded, %.1f s"
-                                       % (sec["iters"], sec["seconds"])}
-    return dt, n, nnz, roof, kernels, cpu, probe, rr_final, extras
+            cpu["secded"] = stats(baseline.time_cg(cols, rows, vals, n, "secded", max(per // 2, 2), runs=CPU_RUNS))
+    return dt, n, nnz, roof, kernels, cpu, probe, rr_final, extras, block_dt
 
 
-def cpp_job(args, spec, mode, fmt, profile):
-    """One fixed-iteration run of the C++ driver (host/cg-csr | cg-coo --bench W,K) as a child of
-    this rank's process: the row-partitioned path is implemented once, in C++ (HIPContext.cpp,
-    comm*.cpp over RCCL); every rank of the launcher starts the same executable with its own
-    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and rank 0's stdout carries the result.
-    W untimed iterations, then K timed ones bracketed by a barrier + device synchronisation on
-    both sides, the slowest rank's time (CGContextExt::run_fixed)."""
-    import re
+def agree_codes(code):
+    """Every rank of the launcher learns every rank's exit status of the job just run (one all-gather over a
+    gloo group on the launcher's own store: CPU only, nothing to do with the job's own transports), so that
+    all ranks take the same decision about it.  One rank: [code]."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return [int(code)]
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+    t = torch.zeros(world, dtype=torch.int64)
+    t[int(os.environ.get("RANK", "0"))] = int(code)
+    dist.all_reduce(t)
+    return [int(v) for v in t]
+
+
+def run_cpp(cmd, env):
     import subprocess
-    exe = os.path.join(ROOT, "abft_sparse_cg_amd", "host", "cg-" + fmt)
-    if not os.path.exists(exe):
-        raise SystemExit("%s not built (make -C abft_sparse_cg_amd/host)" % exe)
-    env = dict(os.environ)
-    if profile:
-        env["ABFT_BENCH_PROFILE"] = "1"
-    cmd = [exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"]
-    p = subprocess.run(cmd, capture_output=True, text=True, env=env)
-    replay = env.get("ABFT_CG_GRAPH", "1") != "0"
-    if p.returncode != 0 and replay:
-        # One fallback, reported in the output line, never silent: the iteration replayed as a hipGraph
-        # with RCCL collectives inside has only ever run at world size 1 on the builder's boxes.  If the
-        # job fails (every rank's child ends then: the one that noticed exits 70, its peers lose it), all
-        # ranks repeat it once with the eager enqueue.
-        sys.stderr.write("rank %s: %s failed with status %d; once more with ABFT_CG_GRAPH=0\n%s\n"
-                         % (os.environ.get("RANK", "0"), " ".join(cmd), p.returncode, p.stderr[-1500:]))
-        env["ABFT_CG_GRAPH"] = "0"
-        replay = False
-        p = subprocess.run(cmd, capture_output=True, text=True, env=env)
-    if p.returncode != 0:
-        sys.stderr.write(p.stdout[-2000:] + p.stderr[-4000:])
-        raise SystemExit("rank %s: %s exited with status %d" % (os.environ.get("RANK", "0"), " ".join(cmd), p.returncode))
-    out = {"stderr": p.stderr, "graph_replay": replay}
+    return subprocess.run(cmd, capture_output=True, text=True, env=env)
+
+
+def parse_cpp(p):
+    """rank 0's stdout of `cg-* --bench` -> dict (other ranks: their stdout is discarded by the backend)"""
+    import re
+    out = {"stderr": p.stderr}
     m = re.search(r"^bench: ranks (\d+) warmup (\d+) steps (\d+) seconds ([0-9.]+) iterations_per_second ([0-9.]+) rr (\S+)$",
                   p.stdout, re.M)
-    if m:  # rank 0 (the other ranks' stdout is discarded by the backend)
+    if m:
         out.update(ranks=int(m.group(1)), seconds=float(m.group(4)), rr=float.fromhex(m.group(6)))
         h = re.search(r"^matrix size +=\s+(\d+) x", p.stdout, re.M)
         z = re.search(r"^number of non-zeros +=\s+(\d+) ", p.stdout, re.M)
@@ -290,7 +301,68 @@ def cpp_job(args, spec, mode, fmt, profile):
         if q:
             out["spmv"] = {"spmvs": int(q.group(1)), "brackets": int(q.group(2)), "total_us": float(q.group(3)),
                            "rows": int(q.group(4)), "nnz": int(q.group(5))}
+        # what each rank used for the two all-reduces and the exchange, and what RCCL itself says about
+        # its communicator (HIPContext.cpp run_fixed): the record of an unattended multi-GPU run
+        out["transport"] = re.findall(r"^bench_transport: (.*)$", p.stdout, re.M)
     return out
+
+
+def cpp_job(args, spec, mode, fmt, profile):
+    """One fixed-iteration run of the C++ driver (host/cg-csr | cg-coo --bench W,K) as a child of
+    this rank's process: the row-partitioned path is implemented once, in C++ (HIPContext.cpp,
+    comm*.cpp over RCCL); every rank of the launcher starts the same executable with its own
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and rank 0's stdout carries the result.
+    W untimed iterations, then K timed ones bracketed by a barrier + device synchronisation on
+    both sides, the slowest rank's time (CGContextExt::run_fixed).
+
+    If the job fails on ANY rank with the iteration replayed as a hipGraph (the default), ALL ranks
+    -- they agree on it, agree_codes -- repeat it once with ABFT_CG_GRAPH=0, and the failed attempt goes
+    into the output line as `first_attempt` (every rank's status, rank 0's stderr tail): an abort in the
+    replay path is then a finding in the record, never just a changed label."""
+    exe = os.path.join(ROOT, "abft_sparse_cg_amd", "host", "cg-" + fmt)
+    if not os.path.exists(exe):
+        raise SystemExit("%s not built (make -C abft_sparse_cg_amd/host)" % exe)
+    env = dict(os.environ)
+    if profile:
+        env["ABFT_BENCH_PROFILE"] = "1"
+    cmd = [exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"]
+    rank = os.environ.get("RANK", "0")
+    p = run_cpp(cmd, env)
+    codes = agree_codes(p.returncode)
+    replay = env.get("ABFT_CG_GRAPH", "1") != "0"
+    first_attempt = None
+    if any(codes) and replay:
+        first_attempt = {"graph_replay": True, "returncodes_by_rank": codes, "rank0_stderr_tail": p.stderr[-1500:],
+                         "note": "status 70 = the first hipGraph replay did not finish within 180 s "
+                                 "(HIPContext.cpp run_fixed); ranks that lose a peer end with other codes"}
+        sys.stderr.write("rank %s: %s failed (statuses by rank: %s); all ranks once more with ABFT_CG_GRAPH=0\n%s\n"
+                         % (rank, " ".join(cmd), codes, p.stderr[-1500:]))
+        env["ABFT_CG_GRAPH"] = "0"
+        replay = False
+        p = run_cpp(cmd, env)
+        codes = agree_codes(p.returncode)
+    if any(codes):
+        sys.stderr.write(p.stdout[-2000:] + p.stderr[-4000:])
+        raise SystemExit("rank %s: %s exited with status %d (statuses by rank: %s)" % (rank, " ".join(cmd), p.returncode, codes))
+    out = parse_cpp(p)
+    out["graph_replay"] = replay
+    if first_attempt:
+        out["first_attempt"] = first_attempt
+    return out
+
+
+def one_rank_rr(args, spec, mode, fmt):
+    """The same W + K iterations by ONE process on rank 0's GPU: the rr a multi-rank job must reproduce
+    (to 1e-10: the shard sums group the additions differently) if its ranks solved the same system."""
+    exe = os.path.join(ROOT, "abft_sparse_cg_amd", "host", "cg-" + fmt)
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ABFT_COMM_FORCE", "ABFT_HIP_GPUS", "ABFT_BENCH_PROFILE",
+                        "TORCHELASTIC_USE_AGENT_STORE")}
+    env.setdefault("ABFT_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+    p = run_cpp([exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"], env)
+    if p.returncode != 0:
+        return {"error": "one-rank run exited with status %d: %s" % (p.returncode, p.stderr[-600:])}
+    return parse_cpp(p)
 
 
 EXTRA_SPEC_MULTI = os.environ.get("ABFT_BENCH_EXTRA_SPEC", "random:4194304,24,1")  # (override: tests)
@@ -309,10 +381,22 @@ def multi(args):
     if rank != 0:
         return None
 
-    def leg(job, fmt, mode):
+    def leg(job, spec, fmt, mode):
         d = {"N": job["N"], "nnz": job["nnz"], "graph_replay": job["graph_replay"],
              "it_per_s": round(args.steps / job["seconds"], 2),
-             "ms_per_step": round(job["seconds"] / args.steps * 1e3, 4), "rr_after_last_step": job["rr"]}
+             "ms_per_step": round(job["seconds"] / args.steps * 1e3, 4), "rr_after_last_step": job["rr"],
+             "transport_by_rank": job.get("transport", [])}
+        if "first_attempt" in job:
+            d["first_attempt"] = job["first_attempt"]
+        if world > 1 and os.environ.get("ABFT_BENCH_RR_CHECK", "1") != "0":
+            # self-validation: the same iterations by one process on rank 0's GPU
+            one = one_rank_rr(args, spec, mode, fmt)
+            if "rr" in one:
+                rel = abs(job["rr"] - one["rr"]) / abs(one["rr"]) if one["rr"] else float("inf")
+                d["rr_check"] = {"one_rank_rr": one["rr"], "rel_diff": rel, "tolerance": 1e-10, "ok": bool(rel <= 1e-10),
+                                 "one_rank_it_per_s": round(args.steps / one["seconds"], 2)}
+            else:
+                d["rr_check"] = {"ok": False, "error": one.get("error", "no bench line")}
         sp = job.get("spmv")
         if sp and sp["spmvs"]:
             us = sp["total_us"] / sp["spmvs"]  # per SpMV of rank 0's shard (all its launches)
@@ -322,7 +406,7 @@ def multi(args):
                                "achieved": round(byts / us / 1e3, 1), "unit": "GB/s",
                                "frac": round(byts / us / 1e3 / HBM_PEAK_GBPS, 4)}
         return d
-    return head, leg(head, args.fmt, args.mode), (leg(extra, "csr", "secded") if extra else None)
+    return head, leg(head, args.spec, args.fmt, args.mode), (leg(extra, EXTRA_SPEC_MULTI, "csr", "secded") if extra else None)
 
 
 def main():
@@ -332,9 +416,12 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic"}
     if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("ABFT_BENCH_SHARDED") != "1":
-        dt, n, nnz, roof, kernels, cpu, probe, rr, extras = single(args)
+        dt, n, nnz, roof, kernels, cpu, probe, rr, extras, block_dt = single(args)
         out = dict(base)
         out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
+                    "blocks": len(block_dt), "value_min": round(args.steps / max(block_dt), 2),
+                    "value_max": round(args.steps / min(block_dt), 2),
+                    "value_is": "median of %d back-to-back blocks of %d timed steps" % (len(block_dt), args.steps),
                     "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec)
                                if args.fmt == "csr" else "cg-coo -t hip -m %s, synthetic %s" % (args.mode, args.spec),
                                "N": n, "nnz": nnz, "format": args.fmt, "mode": args.mode, "parallelism": "1 GPU",
@@ -363,12 +450,16 @@ def main():
                                "parallelism": "%d ranks (one process per GPU, C++ host over RCCL): output blocks cut by "
                                               "non-zeros, exchange of the search vector (all-gather: RCCL; halo windows: "
                                               "shared host memory) + 2 all-reduces per iteration (peer board in shared "
-                                              "host memory, RCCL if that fails its start-up test), "
-                                              "scalars device-resident, iteration %s" % (
+                                              "host memory, RCCL if that fails its start-up test; what each rank used: "
+                                              "transport_by_rank), scalars device-resident, iteration %s" % (
                                                   args.gpus, "replayed as a hipGraph" if hl["graph_replay"] else
                                                   "enqueued eagerly (the graph replay failed on this stack)"),
                                "rr_after_last_step": hl["rr_after_last_step"]},
-                    "roofline": roof, "cpu_baseline": None})
+                    "roofline": roof, "cpu_baseline": None,
+                    # the record of an unattended run: what carried it, and that its ranks solved the same system
+                    "transport_by_rank": hl["transport_by_rank"], "rr_check": hl.get("rr_check")})
+        if "first_attempt" in hl:
+            out["first_attempt"] = hl["first_attempt"]
         if xl:
             xl["workload"] = "cg-csr -t hip -m secded, synthetic %s (BASELINE.json configs[3])" % EXTRA_SPEC_MULTI
             out["extra_legs"] = {"config4": xl}

@@ -46,9 +46,10 @@ def _reference_rhs(n):
     return generators.reference_rhs(n)
 
 
-def time_cg(cols, rows, vals, n, mode, iters, threads=None):
-    """-> dict(kind, iters, seconds, it_per_s, cores).  Runs `iters` CG iterations
-    (conv threshold 0) from x=0, b = deterministic rhs."""
+def time_cg(cols, rows, vals, n, mode, iters, threads=None, runs=1):
+    """-> dict(kind, iters, seconds, it_per_s, it_per_s_runs, cores).  Runs `iters` CG iterations
+    (conv threshold 0) from x=0, b = deterministic rhs, `runs` times on one matrix (the reference's
+    run_benchmark repeats whole program runs; its clock, like this one, covers the CG loop only)."""
     threads = threads or host_cores()
     os.environ["OMP_NUM_THREADS"] = str(threads)
     try:  # the OpenMP runtime reads the variable once; set the count directly for later calls
@@ -74,10 +75,13 @@ def time_cg(cols, rows, vals, n, mode, iters, threads=None):
         L.ref_matrix_destroy.argtypes = [C.c_void_p, C.c_void_p]
         ctx = L.ref_create(mode.encode())
         mat = L.ref_matrix_create(ctx, _p(cols, u32p), _p(rows, u32p), _p(vals, f64p), n, len(vals))
-        t0 = time.perf_counter()
-        it = L.ref_cg(ctx, mat, _p(b, f64p), _p(x, f64p), _p(r, f64p), _p(p, f64p), _p(w, f64p), n, iters, 0.0,
-                      _p(hist, f64p))
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(max(runs, 1)):
+            x[:] = 0.0
+            t0 = time.perf_counter()
+            it = L.ref_cg(ctx, mat, _p(b, f64p), _p(x, f64p), _p(r, f64p), _p(p, f64p), _p(w, f64p), n, iters, 0.0,
+                          _p(hist, f64p))
+            dts.append(time.perf_counter() - t0)
         L.ref_matrix_destroy(ctx, mat)
         kind = "reference"
     else:
@@ -93,11 +97,16 @@ def time_cg(cols, rows, vals, n, mode, iters, threads=None):
         mat = L.ora_matrix_create(0, modes.index(mode), _p(cols, u32p), _p(rows, u32p), _p(vals, f64p), n, n,
                                   len(vals), 0)
         fatal = C.c_int(0)
-        t0 = time.perf_counter()
-        it = L.ora_cg(mat, _p(b, f64p), _p(x, f64p), _p(r, f64p), _p(p, f64p), _p(w, f64p), iters, 0.0,
-                      _p(hist, f64p), threads, C.byref(fatal))
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(max(runs, 1)):
+            x[:] = 0.0
+            t0 = time.perf_counter()
+            it = L.ora_cg(mat, _p(b, f64p), _p(x, f64p), _p(r, f64p), _p(p, f64p), _p(w, f64p), iters, 0.0,
+                          _p(hist, f64p), threads, C.byref(fatal))
+            dts.append(time.perf_counter() - t0)
         L.ora_matrix_destroy(mat)
         kind = "port"
-    return {"kind": kind, "iters": int(it), "seconds": dt, "it_per_s": it / dt if dt > 0 else 0.0,
+    dt = sum(dts)
+    return {"kind": kind, "iters": int(it), "seconds": dt, "it_per_s": it * len(dts) / dt if dt > 0 else 0.0,
+            "it_per_s_runs": [it / d if d > 0 else 0.0 for d in dts],
             "cores": int(threads), "rr_last": float(hist[it - 1]) if it else None}

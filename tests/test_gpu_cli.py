@@ -68,6 +68,33 @@ def test_cli_transcripts_match_reference(fmt):
         compare_transcripts(out.stdout, r["stdout"])
 
 
+@pytest.mark.parametrize("driver", ["cpp", "python"])
+def test_threshold_ambiguous_run_is_flagged(driver):
+    """SURVEY 7 'iteration-count parity': the stop test `rr > threshold` (reference cg.cpp:94) can only
+    come out differently from the reference's when rr lands within rounding of the threshold (the two
+    reductions are tree sums, ~1e-13 relative from the serial sums).  A run in which that happens says so
+    on stderr (stdout stays the reference's); drive it with a threshold crafted from a recorded history."""
+    def go(args, env=None):
+        if driver == "cpp":
+            return run("csr", ["-f", MTX, "-b", "1"] + args, env)
+        return subprocess.run([sys.executable, "-m", "abft_sparse_cg_amd.cg", "-t", "hip", "-f", MTX, "-b", "1"] + args,
+                              capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    hist = run("csr", ["-f", MTX, "-b", "1", "-c", "0", "-i", "12"], {"ABFT_CG_HEX": "1"})
+    assert hist.returncode == 0
+    rrs = [float.fromhex(m.group(1)) for m in re.finditer(r"^rr \d+ (\S+)$", hist.stderr, re.M)]
+    assert len(rrs) == 12 and "threshold-ambiguous" not in hist.stderr
+    # threshold = the rr after iteration 5, to all its digits: the loop stops there (rr > thr is false), flagged
+    amb = go(["-c", "%.17g" % rrs[5], "-i", "12"])
+    assert amb.returncode == 0 and "ran for 6 iterations" in amb.stdout
+    assert amb.stderr.count("note: threshold-ambiguous run") == 1 and "threshold-ambiguous" not in amb.stdout
+    # one part in 1e9 below it: the same six iterations, nothing to flag
+    clear = go(["-c", "%.17g" % (rrs[5] * (1 - 1e-9)), "-i", "12"])
+    assert clear.returncode == 0 and "ran for 6 iterations" not in clear.stdout and "threshold-ambiguous" not in clear.stderr
+    # the default run on this input is nowhere near its threshold
+    plain = go([])
+    assert plain.returncode == 0 and "threshold-ambiguous" not in plain.stderr
+
+
 @pytest.mark.parametrize("fmt", ["csr", "coo"])
 def test_run_tests_script_passes(fmt):
     p = subprocess.run([os.path.join(HOST, "run_tests"), exe(fmt)], capture_output=True, text=True, timeout=900)

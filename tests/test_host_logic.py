@@ -115,3 +115,12 @@ def test_host_collectives_of_the_cpp_multi_gpu_backend(world):
                          timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout == "ok\n"  # rank 0's stdout is the job's; the other ranks' is discarded
+
+
+def test_threshold_ambiguity_rule():
+    """the stop test is flagged exactly when rr is within 1e-12 (relative) of a non-zero threshold"""
+    from abft_sparse_cg_amd.context import threshold_ambiguous
+    assert threshold_ambiguous(1e-3, 1e-3)
+    assert threshold_ambiguous(1e-3 * (1 + 5e-13), 1e-3) and threshold_ambiguous(1e-3 * (1 - 5e-13), 1e-3)
+    assert not threshold_ambiguous(1e-3 * (1 + 1e-11), 1e-3) and not threshold_ambiguous(4863.28, 1e-3)
+    assert not threshold_ambiguous(0.0, 0.0) and not threshold_ambiguous(1e-300, 0.0)  # -c 0: fixed iteration count
