@@ -433,6 +433,9 @@ def test_bench_py_multi_rank_path_runs_the_cpp_driver():
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 0 and d["config"]["N"] == 90000
     assert d["roofline"]["avg_launch_us"] > 0 and "C++ host over RCCL" in d["config"]["parallelism"]
+    # the run says what carried it: one line per rank, with RCCL's own count of its communicator
+    assert len(d["transport_by_rank"]) == 1 and d["transport_by_rank"][0].startswith("rank 0 device 0 allreduce ")
+    assert "ncclCommCount 1" in d["transport_by_rank"][0] and "first_attempt" not in d
 
 
 def test_bench_py_under_the_launcher_two_ranks_two_jobs():
@@ -450,6 +453,11 @@ def test_bench_py_under_the_launcher_two_ranks_two_jobs():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["N"] == 40000 and d["scaling"] == "strong"
     assert d["extra_legs"]["config4"]["N"] == 16384 and d["extra_legs"]["config4"]["it_per_s"] > 0
+    # self-validation of an unattended multi-rank run: transports by rank, and the same W + K iterations by ONE
+    # process give the same rr (1e-10) -- for the headline and for the extra leg
+    assert [t.split()[1] for t in d["transport_by_rank"]] == ["0", "1"] and "first_attempt" not in d
+    for rec in (d, d["extra_legs"]["config4"]):
+        assert rec["rr_check"]["ok"] and rec["rr_check"]["rel_diff"] <= 1e-10, rec["rr_check"]
 
 
 @pytest.mark.parametrize("fmt", ["csr", "coo"])

@@ -242,6 +242,82 @@ def test_panel_layout_on_config2_matches_streaming_layout(amd, gen, monkeypatch)
         pan.close()
 
 
+def test_config4_row_partitioned_shards_equal_the_one_gpu_product(amd, gen):
+    """BASELINE.json configs[3] in its stated form -- cg-csr -m secded row-partitioned over 8 ranks -- shard by
+    shard on the one GPU: for ranks 0, 3 and 7 the shard is planned by the product's planner
+    (host/partition.cpp: abft_plan_shard), its row block generated alone (abft_gen_fill: what a rank's host does,
+    CGContextExt::create_matrix_rows), created with abft_hip_matrix_create_shard (gather indices re-based to the
+    slot-padded gathered vector, events carrying global element indices) and multiplied against the gathered
+    vector: the slice of the one-GPU y bit for bit, before and after two injected flips, which are reported
+    with their GLOBAL index and repaired (SURVEY 8e 'ECC/event semantics'; reference
+    CSR/CPUContext.cpp:353-411 per shard)."""
+    import ctypes as C
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _partition_worker import plan
+    spec, G = "random:4194304,24,1", 8
+    mat = gen.generate(spec)
+    cols, rows, vals, n = mat
+    x = np.random.default_rng(12).standard_normal(n)
+    one = Run(amd, "csr", "secded", mat)
+    try:
+        y_full = one.spmv(x)
+        assert one.events == []
+    finally:
+        one.close()
+    L = C.CDLL(gen.LIB_PATH)
+    block_bounds = gen.partition(spec, G)  # the cut every rank's host makes without holding the matrix
+    for k in (0, 3, 7):
+        p = plan(L, 0, cols, rows, vals, n, G, k)
+        assert [int(b) for b in p["bounds"]] == block_bounds
+        b0, b1 = block_bounds[k], block_bounds[k + 1]
+        first, cnt = p["first"], p["nnz"]
+        assert (p["out0"], p["n_loc"]) == (b0, b1 - b0) and p["n_pad"] == G * p["slot"]
+        bc, br, bv, _ = gen.generate(spec, b0, b1)  # this rank's rows only
+        assert len(bv) == cnt and np.array_equal(bc, cols[first:first + cnt]) and np.array_equal(br, rows[first:first + cnt])
+        assert np.array_equal(bv.view(np.uint64), vals[first:first + cnt].view(np.uint64))
+        assert np.array_equal(p["lout"], br - b0)
+        # an eighth of the elements each (the cut is by non-zeros), every other rank's slot read (scattered columns)
+        assert abs(cnt - len(vals) / G) < 1e-3 * len(vals) and p["interior"] == (0, 0)
+        assert all(hi - lo > 0.99 * (block_bounds[g + 1] - block_bounds[g]) for g, (lo, hi) in enumerate(p["need"]) if g != k)
+        events = []
+        ctx = amd.HIPContext("secded", "csr", on_event=lambda ev, fatal: events.extend(ev))
+        try:
+            A = ctx.create_matrix(p["pin"], p["lout"], bv, p["n_loc"], cnt, n_in=p["n_pad"], index_base=first)
+            # 524 288 rows against the 33.5 MB gathered vector: the sweep layout, the smallest row groups
+            # (2 rows per thread: 1 024 workgroups), 2 MB panels (the segments would stay under a tile at 1 MB)
+            assert ctx.matrix_info(A) == ("sweep", 1)
+            npan, width = ctypes.c_int(), ctypes.c_int()
+            from abft_sparse_cg_amd import capi
+            capi.check(capi.load().abft_hip_matrix_panels(A.h, ctypes.byref(npan), ctypes.byref(width)))
+            assert 1 << 18 <= width.value <= 5 << 16 and npan.value == -(-p["n_pad"] // width.value)
+            xpad = np.zeros(p["n_pad"])
+            for g in range(G):
+                xpad[g * p["slot"]:g * p["slot"] + block_bounds[g + 1] - block_bounds[g]] = x[block_bounds[g]:block_bounds[g + 1]]
+            vx, vy = ctx.create_vector(p["n_pad"]), ctx.create_vector(p["n_loc"])
+            ctx.upload(vx, xpad)
+            ctx.spmv(A, vx, vy)
+            want = y_full[b0:b1]
+            assert bits_equal(ctx.download(vy), want), k
+            ctx._drain()
+            assert events == []
+            flips = [(cnt // 5, 3), (cnt - 7, 70 + k)]  # a value bit and a column / check bit, local element indices
+            for i, bit in flips:
+                ctx.inject_at(A, i, [bit])
+            ctx.spmv(A, vx, vy)
+            assert bits_equal(ctx.download(vy), want), k
+            ctx._drain()
+            assert sorted(events) == sorted((2, first + i, bit) for i, bit in flips), (k, events)
+            events.clear()
+            ctx.spmv(A, vx, vy)  # repaired in place: silent now
+            assert bits_equal(ctx.download(vy), want)
+            ctx._drain()
+            assert events == []
+        finally:
+            ctx.close()
+
+
 @pytest.mark.parametrize("spec,rpt", [("random:4194304,24,1", "2"), ("random:4194304,24,1", "16"), (LAP, "16"), (LAP, "8")])
 def test_sweep_layout_full_size_matches_streaming_layout(amd, gen, monkeypatch, spec, rpt):
     """The sweep layout at full size against the streaming layout of the same matrix, every row bit
