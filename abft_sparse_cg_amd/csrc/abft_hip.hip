@@ -493,8 +493,9 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
                        SweepBuild &sb) {
   const char *env = getenv("ABFT_HIP_LAYOUT");
   const bool force = env && !strcmp(env, "sweep");
-  if ((env && strcmp(env, "sweep") && strcmp(env, "auto")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0)
-    return false;
+  // (constraints mode too, round 3: the kernel stages the columns and runs the reference's checks in the
+  // summing phase; round 2 sent that mode to the streaming layout, 2.5 x every other mode on config 4)
+  if ((env && strcmp(env, "sweep") && strcmp(env, "auto")) || nnz <= 0 || n_out <= 0) return false;
   if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
   // rows per thread: the group size that keeps the most workgroups per CU busy (up to 4: more did
   // not help), then the fewest rounds, then the smallest groups
@@ -502,6 +503,7 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
     double best = -1.0;
     uint64_t best_rounds = 0;
     for (int rpt : {2, 4, 8, 16}) {  // (1 row per thread, 8 workgroups per CU: 169 vs 128 us on config 4's 1/8 shard)
+      if (rpt == 16 && mode == ABFT_MODE_CONSTRAINTS) continue;  // (its per-row check state does not fit 128 registers there)
       const uint64_t groups = ((uint64_t)n_out + 256u * rpt - 1) / (256u * rpt), cap = std::max<uint64_t>(capacity(rpt), 1);
       const uint64_t rounds = (groups + cap - 1) / cap;
       const double per_cu = std::min(4.0, (double)((groups + rounds - 1) / rounds) / 256.0);
@@ -512,7 +514,7 @@ static bool plan_sweep(int mode, const uint32_t *cols, const uint32_t *rows, int
   }
   if (const char *r = getenv("ABFT_HIP_SWEEP_RPT")) {
     const int v = atoi(r);
-    if (v == 2 || v == 4 || v == 8 || v == 16) sb.rpt = v;
+    if (v == 2 || v == 4 || v == 8 || (v == 16 && mode != ABFT_MODE_CONSTRAINTS)) sb.rpt = v;
   }
   // entries of the gathered vector per panel: about 1 MB of it (2 MB: 757 vs 743 us on config 4) unless that
   // leaves a segment well under two tiles on average -- the 1/8 row shard of config 4 that one rank
@@ -1676,6 +1678,10 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   if (whole) { c0 = 0; c1 = (int)npan; }
   if (c0 < 0 || c0 >= c1 || (uint32_t)c1 > npan) return set_err(ABFT_ERR_INVALID, "spmv: panels [%d,%d) outside [0,%u)", c0, c1, npan);
   if (!whole && part != ABFT_PART_ALL) return set_err(ABFT_ERR_INVALID, "spmv: a panel range with a row part");
+  // (the order check between a row's last element of one panel and its first of the next lives in the
+  // kernel's registers: a sweep cut into ranges would skip it at the cut)
+  if (!whole && mat->mode == ABFT_MODE_CONSTRAINTS && c1 - c0 < (int)npan)
+    return set_err(ABFT_ERR_INVALID, "spmv: a panel range in constraints mode");
   const bool last_range = (uint32_t)c1 == npan;
   const bool do_fuse = want_fuse && last_range;
   TileSpan span{0u, mat->csr.nblk, 0u, mat->csr.nblk};

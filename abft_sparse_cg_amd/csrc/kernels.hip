@@ -122,9 +122,11 @@ __device__ __noinline__ EccWords<FMT> ecc_cold(EccWords<FMT> e, uint32_t gidx, E
 }
 
 // the element index an event line carries: the caller's, global across shards
-__device__ __forceinline__ uint32_t event_index(const CsrDev &A, uint32_t i) {
-  const uint32_t o = A.orig_index ? A.orig_index[i] : i;
+__device__ __forceinline__ uint32_t event_index_of_orig(const CsrDev &A, uint32_t o) {
   return A.gidx ? A.gidx[o] : A.index_base + o;
+}
+__device__ __forceinline__ uint32_t event_index(const CsrDev &A, uint32_t i) {
+  return event_index_of_orig(A, A.orig_index ? A.orig_index[i] : i);
 }
 __device__ __forceinline__ uint32_t event_index(const CooDev &A, uint32_t j) {
   const uint32_t o = A.orig_index[j];
@@ -1242,7 +1244,7 @@ __device__ __forceinline__ uint32_t board_min(const BoardView &v) {
 // (CSR/CPUContext.cpp:115-133 and variants).  RPT rows per thread: 256 * RPT rows per
 // workgroup, chosen at create time so that all groups are resident at once.
 template <int MODE, int RPT>
-__global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
+__global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS) ? 4 : 5) void spmv_sweep_kernel(CsrDev A, SweepLayout L,
                                                                 const double *__restrict__ x, double *__restrict__ y,
                                                                 EventRing ev, FuseOut fuse, bool fused, uint32_t c0,
                                                                 uint32_t c1) {
@@ -1256,9 +1258,12 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
   // buffer now being written, before anyone passed tile t's barrier)
   // (where 5 workgroups per CU are wanted -- every RPT but 16 -- two 16 KB buffers would not fit
   // beside each other five times: one buffer, two barriers)
-  constexpr bool TWO = RPT == 16 || EPT <= 4;
+  constexpr bool TWO = (RPT == 16 || EPT <= 4) && MODE != MODE_CONSTRAINTS;  // (constraints stages the columns too: one buffer set)
   __shared__ __attribute__((aligned(16))) double s_buf[TWO ? 2 : 1][TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_col[2];
+  // constraints mode: the staged columns too (the checks of reference CSR/CPUContext.cpp:186-200 run in
+  // the summing phase, element by element in the row's order)
+  constexpr bool CONS = MODE == MODE_CONSTRAINTS;
+  __shared__ __attribute__((aligned(16))) uint32_t s_colbuf[CONS ? (TWO ? 2 : 1) : 1][CONS ? TILE : 2];
   uint32_t par = 0;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1298,6 +1303,23 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + 64u * (uint32_t)j;
       acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
+    }
+    // constraints mode, per row of this thread: the column of its last element so far (a row's elements
+    // sit in several panels; the order check between the last one of a panel and the first of the next
+    // needs it), whether there is one, and whether the row has already failed a check
+    uint32_t cons_last[CONS ? RPT : 1];
+    uint32_t cons_has = 0u, cons_dead = 0u;
+    if (CONS) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        cons_last[j] = 0u;
+        const uint32_t row = out0 + 64u * (uint32_t)j;
+        if (row < A.n_out) {  // the two row-pointer checks (reference CSR/CPUContext.cpp:173-182)
+          const uint32_t rs = A.rowptr[row], re = A.rowptr[row + 1];
+          if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, row, FMT_CSR); cons_dead |= 1u << j; }
+          else if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, row, FMT_CSR); cons_dead |= 1u << j; }
+        }
+      }
     }
     const uint32_t *wb = L.wbase + 4u * (size_t)g * L.npanels;
     CsrTileRegs<EPT> tr_cur, tr_nxt;
@@ -1362,6 +1384,7 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
           const uint32_t b = lo & ~1u;
           const uint32_t hi = min(e1, b + TILE);
           double *s_prod = s_buf[TWO ? par : 0u];
+          uint32_t *s_col = s_colbuf[CONS && TWO ? par : 0u];
           par ^= 1u;
           if (!TWO) __syncthreads();
           if (PF) {
@@ -1395,7 +1418,36 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
             const uint32_t a0 = max(start[j], lo), a1 = min(start[j] + cj, hi);
             if (a0 < a1) {
               double t = acc[j];
-              csr_row_sum<MODE, ABFT_CFG_SWEEP_SHORT_SUMS>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
+              if (CONS) {
+                // the row's elements of this panel and tile, in the row's order: column inside the vector,
+                // column above its predecessor's (reference CSR/CPUContext.cpp:186-200; the predecessor of a
+                // panel's first element is the last element of the row in an earlier panel)
+                if (!((cons_dead >> j) & 1u)) {
+                  const uint32_t row = out0 + 64u * (uint32_t)j;
+                  uint32_t prev = cons_last[j];
+                  bool has = (cons_has >> j) & 1u;
+                  for (uint32_t i = a0; i < a1; i++) {
+                    const uint32_t col = s_col[i - b];
+                    if (has && col <= prev) {  // reported at the predecessor: the caller's element before this one
+                      push_event(ev, ABFT_EV_COL_ORDER, event_index_of_orig(A, A.orig_index[i] - 1u), row, FMT_CSR);
+                      cons_dead |= 1u << j;
+                      break;
+                    }
+                    if (col >= A.n_in) {
+                      push_event(ev, ABFT_EV_COL_SIZE, event_index(A, i), row, FMT_CSR);
+                      cons_dead |= 1u << j;
+                      break;
+                    }
+                    t += s_prod[i - b];
+                    prev = col;
+                    has = true;
+                  }
+                  cons_last[j] = prev;
+                  cons_has |= 1u << j;
+                }
+              } else {
+                csr_row_sum<MODE, ABFT_CFG_SWEEP_SHORT_SUMS>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
+              }
               acc[j] = t;
             }
           }
@@ -1409,7 +1461,7 @@ __global__ __launch_bounds__(ABFT_BLOCK, RPT == 16 ? 4 : 5) void spmv_sweep_kern
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + 64u * (uint32_t)j;
-      if (o < A.n_out) {
+      if (o < A.n_out && !(CONS && ((cons_dead >> j) & 1u))) {  // (a row that failed a check is left alone, as in the streaming kernel)
         y[o] = acc[j];
         if (fused) dsum += x[fuse.x_off + o] * acc[j];
       }
@@ -1450,7 +1502,8 @@ template <int MODE, int RPT> static int sweep_occupancy_inst() {
 // one switch for both uses: OP(MODE, RPT)
 #define ABFT_SWEEP_DISPATCH(OP)                                                                    \
   switch (mode * 100 + rpt) {                                                                      \
-    ABFT_SWEEP_MODE(OP, MODE_NONE) ABFT_SWEEP_MODE(OP, MODE_SED) ABFT_SWEEP_MODE(OP, MODE_SEC7)    \
+    ABFT_SWEEP_MODE(OP, MODE_NONE) ABFT_SWEEP_MODE(OP, MODE_CONSTRAINTS) ABFT_SWEEP_MODE(OP, MODE_SED)  \
+    ABFT_SWEEP_MODE(OP, MODE_SEC7)                                                                 \
     ABFT_SWEEP_MODE(OP, MODE_SEC8) ABFT_SWEEP_MODE(OP, MODE_SECDED)                                \
     default: break;                                                                                \
   }

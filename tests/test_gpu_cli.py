@@ -79,17 +79,21 @@ def test_threshold_ambiguous_run_is_flagged(driver):
             return run("csr", ["-f", MTX, "-b", "1"] + args, env)
         return subprocess.run([sys.executable, "-m", "abft_sparse_cg_amd.cg", "-t", "hip", "-f", MTX, "-b", "1"] + args,
                               capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(os.environ, **(env or {})))
-    hist = run("csr", ["-f", MTX, "-b", "1", "-c", "0", "-i", "12"], {"ABFT_CG_HEX": "1"})
+    hist = run("csr", ["-f", MTX, "-b", "1", "-c", "0", "-i", "60"], {"ABFT_CG_HEX": "1"})
     assert hist.returncode == 0
     rrs = [float.fromhex(m.group(1)) for m in re.finditer(r"^rr \d+ (\S+)$", hist.stderr, re.M)]
-    assert len(rrs) == 12 and "threshold-ambiguous" not in hist.stderr
-    # threshold = the rr after iteration 5, to all its digits: the loop stops there (rr > thr is false), flagged
-    amb = go(["-c", "%.17g" % rrs[5], "-i", "12"])
-    assert amb.returncode == 0 and "ran for 6 iterations" in amb.stdout
+    assert len(rrs) == 60 and "threshold-ambiguous" not in hist.stderr
+    # (rr is not monotone, and the first values lie above the initial b.b ~ n / 3: take an iteration whose rr is
+    # lower than everything before it)
+    k = next(i for i in range(20, 60) if rrs[i] < min(rrs[:i]) and rrs[i] < 1000.0)
+    # threshold = the rr after iteration k, to all its digits: the loop stops there (rr > thr is false), flagged
+    amb = go(["-c", "%.17g" % rrs[k], "-i", "60"])
+    assert amb.returncode == 0 and "ran for %d iterations" % (k + 1) in amb.stdout, amb.stdout[-300:]
     assert amb.stderr.count("note: threshold-ambiguous run") == 1 and "threshold-ambiguous" not in amb.stdout
-    # one part in 1e9 below it: the same six iterations, nothing to flag
-    clear = go(["-c", "%.17g" % (rrs[5] * (1 - 1e-9)), "-i", "12"])
-    assert clear.returncode == 0 and "ran for 6 iterations" not in clear.stdout and "threshold-ambiguous" not in clear.stderr
+    # one part in 1e9 below it: at least one iteration more, nothing to flag
+    clear = go(["-c", "%.17g" % (rrs[k] * (1 - 1e-9)), "-i", "60"])
+    assert clear.returncode == 0 and "ran for %d iterations" % (k + 1) not in clear.stdout
+    assert "threshold-ambiguous" not in clear.stderr
     # the default run on this input is nowhere near its threshold
     plain = go([])
     assert plain.returncode == 0 and "threshold-ambiguous" not in plain.stderr
@@ -387,6 +391,15 @@ def test_bench_mode_device_scalars_and_graph_replay(spec, mode):
     forced = run_ranks(1, ["-t", "hip"] + base)
     assert forced.returncode == 0, forced.stderr[-800:]
     assert abs(bench_line(forced.stdout)[4] - want) <= 1e-10 * want and "over RCCL" in forced.stderr
+    # north_star's transport spelled out -- both scalar all-reduces and the exchange as RCCL calls inside the
+    # replayed graph (what the start-up test falls back to when the shared-memory board misbehaves): known good
+    rccl = run_ranks(1, ["-t", "hip"] + base, env={"ABFT_COMM_ALLREDUCE": "rccl", "ABFT_COMM_EXCHANGE": "rccl"})
+    assert rccl.returncode == 0, rccl.stderr[-800:]
+    assert abs(bench_line(rccl.stdout)[4] - want) <= 1e-10 * want
+    t = re.findall(r"^bench_transport: (.*)$", rccl.stdout, re.M)
+    assert len(t) == 1 and " allreduce rccl " in t[0] and "-over-rccl graph 1 ncclCommCount 1" in t[0], t
+    t = re.findall(r"^bench_transport: (.*)$", forced.stdout, re.M)
+    assert len(t) == 1 and " allreduce board-in-kernel-tails " in t[0] and "graph 1 ncclCommCount 1" in t[0], t
     for world in (2, 3):
         many = run_ranks(world, ["-t", "hip"] + base, ("--one-gpu",))
         assert many.returncode == 0, many.stderr[-800:]

@@ -213,6 +213,81 @@ def test_constraints_mode_detects_like_reference(amd, fmt):
     assert fatal_seen > 20
 
 
+@pytest.mark.parametrize("width,rpt,lag", [(16, 8, 2), (7, 2, 0), (64, 4, 1), (100000, 8, 2)])
+def test_constraints_mode_in_the_sweep_layout(amd, width, rpt, lag, monkeypatch):
+    """Round 3: constraints mode runs on the sweep layout too (scattered matrices; round 2 forced the
+    streaming layout there).  The reference's checks (CSR/CPUContext.cpp:173-200) are made in the summing
+    phase in the row's order -- a row's elements sit in several panels, so the order check between the last
+    element of one panel and the first of the next goes through a register per row.  Forced here with tiny
+    panels: every index-bit flip of several elements -> the oracle's events (kind, caller's index) and, when
+    the flip passes the checks, the oracle's y bit for bit; then the two row-pointer checks."""
+    from abft_sparse_cg_amd import capi
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep")
+    monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", str(width))
+    monkeypatch.setenv("ABFT_HIP_SWEEP_RPT", str(rpt))
+    monkeypatch.setenv("ABFT_HIP_SWEEP_LAG", str(lag))
+    cols, rows, vals, n = random_spd(50, 6, seed=4)
+    x = rhs(n, 5)
+    fatal_seen = passed = 0
+    kinds = set()
+    for index in (0, 5, len(vals) - 1, len(vals) // 3, len(vals) // 2 + 1):
+        for bit in range(64, 96):
+            o = OracleMatrix(CSR, "constraints", cols, rows, vals, n)
+            o.inject(index, [bit])
+            h = Hip(amd, CSR, "constraints", cols, rows, vals, n)
+            try:
+                assert h.ctx.matrix_info(h.A)[0] == "sweep"
+                h.ctx.inject_at(h.A, index, [bit])
+                y, want = h.spmv(x), o.spmv(x)
+                ev, fatal = h.take_events()
+                assert (ev, fatal) == o.events(), (index, bit, ev, o.events())
+                fatal_seen += fatal
+                if fatal:
+                    kinds.add(ev[0][0])
+                else:
+                    passed += 1
+                    assert bits_equal(y, want), (index, bit)
+            finally:
+                h.close()
+    assert fatal_seen > 20 and passed > 5 and {7, 8} <= kinds  # column size and column order both seen
+    # the clean matrix, twice (fused dot on the second pass), on the ragged one too
+    for mat in ("ragged", "rnd300", "tail_empty"):
+        c2, r2, v2, n2 = MATS[mat]()
+        x2 = rhs(n2, 11) - 0.5
+        o = OracleMatrix(CSR, "constraints", c2, r2, v2, n2)
+        h = Hip(amd, CSR, "constraints", c2, r2, v2, n2)
+        try:
+            if mat != "ragged" or width <= 64:
+                assert h.ctx.matrix_info(h.A)[0] == "sweep", mat
+            assert bits_equal(h.spmv(x2), o.spmv(x2)) and h.take_events() == ([], False)
+            h.ctx.spmv(h.A, h.vx, h.vy)
+            d = h.ctx.dot(h.vx, h.vy)
+            yy = h.ctx.download(h.vy)
+            assert bits_equal(yy, o.spmv(x2)) and abs(d - ora_dot(x2, yy)) <= 1e-13 * float(np.abs(x2 * yy).sum()) + 1e-300
+        finally:
+            h.close()
+    # row pointers: the reference's two checks, same first fatal event
+    cols, rows, vals, n = random_spd(120, 6, seed=8)
+    x = rhs(n, 5)
+    rk = set()
+    for row, mask in ((7, 1 << 30), (1, 1 << 5), (n, 1 << 29), (60, 1 << 9), (119, 1 << 31)):
+        o = OracleMatrix(CSR, "constraints", cols, rows, vals, n)
+        o._view("ora_matrix_csr_rowptr", np.uint32, n + 1)[row] ^= np.uint32(mask)
+        h = Hip(amd, CSR, "constraints", cols, rows, vals, n)
+        try:
+            capi.check(h.ctx.L.abft_hip_inject_rowptr(h.A.h, row, mask))
+            h.spmv(x)
+            o.spmv(x)
+            ev, fatal = h.take_events()
+            oev, ofatal = o.events()
+            if ofatal and oev[0][0] in (5, 6):  # (a pointer moved without breaking either check: see DESIGN.md)
+                assert fatal and ev[:1] == oev[:1], (row, mask, ev, oev)
+                rk.add(ev[0][0])
+        finally:
+            h.close()
+    assert {5, 6} <= rk
+
+
 def test_event_queue_overflow_is_reported_not_hidden(amd):
     """More events than the device queue holds (65 536): the drain hands over what was kept and
     fails loudly (ABFT_ERR_RANGE) -- a run past this point would no longer print the reference's
