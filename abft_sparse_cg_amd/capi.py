@@ -89,6 +89,12 @@ SIGNATURES = {
     "abft_hip_peer_board_detach": (C.c_int, [vp]),
     "abft_hip_allreduce_pair_peers": (C.c_int, [vp, vp]),
     "abft_hip_peer_board_failed": (C.c_int, [vp]),
+    "abft_hip_peer_board_ipc_handle_bytes": (C.c_size_t, []),
+    "abft_hip_peer_board_ipc_export": (C.c_int, [vp, vp]),
+    "abft_hip_peer_board_ipc_attach": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double]),
+    "abft_hip_peer_board_device_alloc": (C.c_int, [vp, C.POINTER(vp)]),
+    "abft_hip_peer_board_device_free": (C.c_int, [vp, vp]),
+    "abft_hip_peer_board_attach_device": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_double]),
     "abft_hip_peer_board_fuse": (C.c_int, [vp, C.c_int]),
     "abft_hip_peer_exchange_bytes": (C.c_size_t, [C.c_int, C.c_size_t]),
     "abft_hip_peer_exchange_attach": (C.c_int, [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, vp,

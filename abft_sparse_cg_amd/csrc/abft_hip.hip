@@ -85,8 +85,12 @@ struct abft_hip_ctx {
   std::vector<hipEvent_t> ev_pool;
   // peer board (abft_hip_peer_board_attach): the caller's mapping, its device alias, this rank
   struct {
-    void *host = nullptr;
-    PeerSlot *dev = nullptr;
+    bool attached = false;
+    void *host = nullptr;                   // host-memory board: the caller's mapping
+    PeerSlot *dev = nullptr;                // ... its device alias; device-memory board: this rank's own copy
+    PeerSlot **table = nullptr;             // device-memory board: every rank's copy by rank (device array), else NULL
+    bool own_local = false;                 // the own copy was allocated by abft_hip_peer_board_ipc_export
+    std::vector<void *> opened;             // peers' copies opened over IPC (closed at detach)
     unsigned long long *counter = nullptr;  // device: sequence number of the last all-reduce
     int rank = 0, size = 0;
     unsigned long long timeout_ticks = 0;
@@ -1229,6 +1233,7 @@ extern "C" int abft_hip_vector_length(abft_hip_vector *vec) { return vec ? vec->
 
 static PeerArgs peer_args(const abft_hip_ctx *ctx) {
   PeerArgs P{};
+  P.boards = ctx->peers.table;
   P.board = ctx->peers.dev;
   P.counter = ctx->peers.counter;
   P.fail = reinterpret_cast<uint32_t *>(ctx->peers.dev + 2 * ABFT_PEER_MAX_RANKS);
@@ -1424,7 +1429,7 @@ extern "C" int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_
                    abft_hip_peer_board_bytes());
   if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
     return set_err(ABFT_ERR_RANGE, "peer board: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
-  if (ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: already attached");
+  if (ctx->peers.attached) return set_err(ABFT_ERR_INVALID, "peer board: already attached");
   if (hipHostRegister(shared, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
     return set_err(ABFT_ERR_HIP, "peer board: hipHostRegister of the shared mapping failed");
@@ -1440,6 +1445,7 @@ extern "C" int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_
   }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+  ctx->peers.attached = true;
   ctx->peers.host = shared;
   ctx->peers.dev = (PeerSlot *)dev;
   ctx->peers.counter = counter;
@@ -1449,11 +1455,138 @@ extern "C" int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_
   return ABFT_OK;
 }
 
+// ---- the same board in DEVICE memory, one copy per rank (round 3) ----
+// Every rank allocates a copy in its own GPU's memory; a rank pushes its slot into every copy (remote
+// stores over xGMI between the GPUs of a node) and polls only its own (local loads).  Between
+// processes the copies travel as IPC handles (abft_hip_peer_board_ipc_export / _ipc_attach); inside
+// one process (tests: two contexts standing in for two ranks) as plain pointers
+// (abft_hip_peer_board_attach_device).
+
+static int board_alloc(abft_hip_ctx *ctx, PeerSlot **out) {
+  void *p = nullptr;
+  const size_t bytes = abft_hip_peer_board_bytes();
+  // fine-grained (coherent across devices) where the runtime offers it; the kernel's accesses carry
+  // sc0 sc1 either way
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return set_err(ABFT_ERR_NOMEM, "peer board: %zu bytes of device memory", bytes);
+    }
+  }
+  HIPCHK(hipMemset(p, 0, bytes));
+  HIPCHK(hipDeviceSynchronize());
+  *out = (PeerSlot *)p;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_board_device_alloc(abft_hip_ctx *ctx, void **board) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!board) return set_err(ABFT_ERR_INVALID, "null argument");
+  PeerSlot *p = nullptr;
+  if (int rc = board_alloc(ctx, &p)) return rc;
+  *board = p;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_board_device_free(abft_hip_ctx *ctx, void *board) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (board) HIPCHK(hipFree(board));
+  return ABFT_OK;
+}
+
+static int attach_table(abft_hip_ctx *ctx, void *const *boards, int rank, int size, double timeout_seconds) {
+  PeerSlot **table = nullptr;
+  unsigned long long *counter = nullptr;
+  if (hipMalloc((void **)&table, (size_t)size * sizeof(PeerSlot *)) != hipSuccess ||
+      hipMalloc((void **)&counter, sizeof(*counter)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(table);
+    return set_err(ABFT_ERR_NOMEM, "peer board: table");
+  }
+  HIPCHK(hipMemcpy(table, boards, (size_t)size * sizeof(PeerSlot *), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(counter, 0, sizeof(*counter)));
+  int khz = 0;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
+  ctx->peers.attached = true;
+  ctx->peers.host = nullptr;
+  ctx->peers.dev = (PeerSlot *)boards[rank];
+  ctx->peers.table = table;
+  ctx->peers.counter = counter;
+  ctx->peers.rank = rank;
+  ctx->peers.size = size;
+  ctx->peers.timeout_ticks = (unsigned long long)((timeout_seconds > 0 ? timeout_seconds : 120.0) * 1e3 * khz);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_board_attach_device(abft_hip_ctx *ctx, void *const *boards, int rank, int size,
+                                                 double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
+    return set_err(ABFT_ERR_RANGE, "peer board: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
+  if (!boards) return set_err(ABFT_ERR_INVALID, "null argument");
+  for (int r = 0; r < size; r++)
+    if (!boards[r] || ((uintptr_t)boards[r] & 15u)) return set_err(ABFT_ERR_INVALID, "peer board: copy %d missing or misaligned", r);
+  if (ctx->peers.attached) return set_err(ABFT_ERR_INVALID, "peer board: already attached");
+  return attach_table(ctx, boards, rank, size, timeout_seconds);
+}
+
+extern "C" size_t abft_hip_peer_board_ipc_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
+
+// this rank's copy, allocated here, as an IPC handle for the other processes of the node
+extern "C" int abft_hip_peer_board_ipc_export(abft_hip_ctx *ctx, void *handle) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!handle) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (ctx->peers.attached || ctx->peers.own_local) return set_err(ABFT_ERR_INVALID, "peer board: already attached or exported");
+  PeerSlot *p = nullptr;
+  if (int rc = board_alloc(ctx, &p)) return rc;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return set_err(ABFT_ERR_HIP, "peer board: hipIpcGetMemHandle failed");
+  }
+  memcpy(handle, &h, sizeof(h));
+  ctx->peers.dev = p;
+  ctx->peers.own_local = true;
+  return ABFT_OK;
+}
+
+// `handles`: size x abft_hip_peer_board_ipc_handle_bytes(), by rank (this rank's own entry is not opened)
+extern "C" int abft_hip_peer_board_ipc_attach(abft_hip_ctx *ctx, const void *handles, int rank, int size,
+                                              double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
+    return set_err(ABFT_ERR_RANGE, "peer board: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
+  if (!handles || !ctx->peers.own_local || ctx->peers.attached)
+    return set_err(ABFT_ERR_INVALID, "peer board: export this rank's copy first (once)");
+  std::vector<void *> boards((size_t)size, nullptr);
+  boards[(size_t)rank] = ctx->peers.dev;
+  for (int r = 0; r < size; r++) {
+    if (r == rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char *>(handles) + (size_t)r * sizeof(h), sizeof(h));
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      for (void *q : ctx->peers.opened) (void)hipIpcCloseMemHandle(q);
+      ctx->peers.opened.clear();
+      return set_err(ABFT_ERR_HIP, "peer board: rank %d's copy cannot be mapped into this process (hipIpcOpenMemHandle)", r);
+    }
+    ctx->peers.opened.push_back(p);
+    boards[(size_t)r] = p;
+  }
+  return attach_table(ctx, boards.data(), rank, size, timeout_seconds);
+}
+
 extern "C" int abft_hip_peer_board_detach(abft_hip_ctx *ctx) {
-  if (!ctx || !ctx->peers.host) return ABFT_OK;
+  if (!ctx || (!ctx->peers.attached && !ctx->peers.own_local)) return ABFT_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  (void)hipHostUnregister(ctx->peers.host);
+  if (ctx->peers.host) (void)hipHostUnregister(ctx->peers.host);
+  for (void *q : ctx->peers.opened) (void)hipIpcCloseMemHandle(q);
+  if (ctx->peers.own_local) (void)hipFree(ctx->peers.dev);
+  (void)hipFree(ctx->peers.table);
   (void)hipFree(ctx->peers.counter);
   (void)hipGetLastError();  // (a failed unregister must not surface at the next launch check)
   ctx->peers = {};
@@ -1464,7 +1597,7 @@ extern "C" int abft_hip_peer_board_detach(abft_hip_ctx *ctx) {
 extern "C" int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair) {
   if (int rc = bind(ctx, true)) return rc;
   if (!dev_pair) return set_err(ABFT_ERR_INVALID, "null argument");
-  if (!ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
+  if (!ctx->peers.attached) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
   HIPCHK(launch_peer_allreduce(dev_pair, peer_args(ctx), ctx->stream));
   return ABFT_OK;
 }
@@ -1475,14 +1608,24 @@ extern "C" int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair
 // no kernel of its own.  Every rank must switch at the same point of its call sequence.
 extern "C" int abft_hip_peer_board_fuse(abft_hip_ctx *ctx, int on) {
   if (int rc = bind(ctx, true)) return rc;
-  if (on && !ctx->peers.host) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
+  if (on && !ctx->peers.attached) return set_err(ABFT_ERR_INVALID, "peer board: not attached");
   ctx->peers.fuse = on != 0;
   return ABFT_OK;
 }
 
 // 1 if an all-reduce of this rank gave up waiting for a peer (its result was NaN)
 extern "C" int abft_hip_peer_board_failed(abft_hip_ctx *ctx) {
-  if (!ctx || !ctx->peers.host) return 0;
+  if (!ctx || !ctx->peers.attached) return 0;
+  if (!ctx->peers.host) {  // device-memory board: the flag sits in this rank's own copy
+    uint32_t f = 0;
+    (void)hipSetDevice(ctx->device);
+    if (hipMemcpy(&f, reinterpret_cast<const uint32_t *>(ctx->peers.dev + 2 * ABFT_PEER_MAX_RANKS) + ctx->peers.rank, sizeof(f),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    return f != 0;
+  }
   const volatile uint32_t *fail =
       reinterpret_cast<const volatile uint32_t *>(static_cast<PeerSlot *>(ctx->peers.host) + 2 * ABFT_PEER_MAX_RANKS);
   return fail[ctx->peers.rank] != 0;

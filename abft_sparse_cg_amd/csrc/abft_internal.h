@@ -218,6 +218,7 @@ struct PeerSlot {
 // ... as the tail of a reduction: the block that finishes the shard's sum also takes it over the
 // board (size == 0: no)
 struct PeerArgs {
+  PeerSlot *const *boards;  // replicated board (device memory): every rank's copy, by rank (device table); else NULL
   PeerSlot *board;
   unsigned long long *counter;
   uint32_t *fail;

@@ -266,27 +266,45 @@ __device__ __forceinline__ unsigned long long peer_check_word(unsigned long long
 
 __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, const PeerArgs &P) {
   __shared__ double s_pv[2][ABFT_PEER_MAX_RANKS];
+  __shared__ double s_mine[2];
   __shared__ unsigned long long s_pseq;
   __shared__ uint32_t s_pbad;
   const uint32_t t = threadIdx.x;
   if (t == 0) {
     const unsigned long long seq = *P.counter + 1ull;  // written by the previous all-reduce on this stream
-    PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
-    // two 16-byte stores, {v0, v1} and {sequence number, check word}, not waited for and in no
-    // particular order: a reader takes a slot only when its check word fits the sequence number AND
-    // the values next to it, so it cannot pair a new number with an old value; it polls whole slots,
-    // which makes an all-reduce one store and (mostly) one load across the link instead of a store,
-    // its acknowledgement, a flag, a poll and a load
-    u64x2 *half = reinterpret_cast<u64x2 *>(mine);
-    sys_store_b128(half, u64x2{(unsigned long long)__double_as_longlong(v0), (unsigned long long)__double_as_longlong(v1)});
-    sys_store_b128(half + 1, u64x2{seq, peer_check_word(seq, v0, v1)});
+    if (!P.boards) {
+      PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
+      // two 16-byte stores, {v0, v1} and {sequence number, check word}, not waited for and in no
+      // particular order: a reader takes a slot only when its check word fits the sequence number AND
+      // the values next to it, so it cannot pair a new number with an old value; it polls whole slots,
+      // which makes an all-reduce one store and (mostly) one load across the link instead of a store,
+      // its acknowledgement, a flag, a poll and a load
+      u64x2 *half = reinterpret_cast<u64x2 *>(mine);
+      sys_store_b128(half, u64x2{(unsigned long long)__double_as_longlong(v0), (unsigned long long)__double_as_longlong(v1)});
+      sys_store_b128(half + 1, u64x2{seq, peer_check_word(seq, v0, v1)});
+    }
+    s_mine[0] = v0;
+    s_mine[1] = v1;
     s_pseq = seq;
     s_pbad = 0u;
   }
   __syncthreads();
   const unsigned long long seq = s_pseq;
+  // Replicated board (device memory, one copy per rank, the peers' copies mapped over IPC): lane r
+  // PUSHES this rank's slot into rank r's copy -- remote stores, which the fabric posts -- and every
+  // rank polls only its OWN copy, in its own memory.  Same slot format, same check word.
+  const PeerSlot *poll = P.board;
+  if (P.boards) {
+    if (t < (uint32_t)P.size) {
+      const double m0 = s_mine[0], m1 = s_mine[1];
+      u64x2 *half = reinterpret_cast<u64x2 *>(P.boards[t] + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank);
+      sys_store_b128(half, u64x2{(unsigned long long)__double_as_longlong(m0), (unsigned long long)__double_as_longlong(m1)});
+      sys_store_b128(half + 1, u64x2{seq, peer_check_word(seq, m0, m1)});
+    }
+    poll = P.boards[P.rank];
+  }
   if (t < (uint32_t)P.size) {
-    const u64x2 *half = reinterpret_cast<const u64x2 *>(P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + t);
+    const u64x2 *half = reinterpret_cast<const u64x2 *>(poll + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + t);
     const unsigned long long t0 = (unsigned long long)wall_clock64();
     bool ok = false;
     double a = 0.0, b = 0.0;

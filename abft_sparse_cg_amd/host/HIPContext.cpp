@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 
 #include <chrono>
 #include <cmath>
@@ -18,7 +19,7 @@
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
     r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
-    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), peers_ok_(false), fuse_allreduce_(false),
+    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), board_kind_("board"), peers_ok_(false), fuse_allreduce_(false),
     one_node_(false), xchg_map_(NULL), xchg_bytes_(0), peer_xchg_ok_(false), has_interior_(false), fixed_beside_(false)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
@@ -106,21 +107,61 @@ void HIPContextBase::setup_peer_board()
   for (int r = 0; r < size; r++)
     one_node_ = one_node_ && !memcmp(&hosts[(size_t)r * sizeof(host)], host, sizeof(host));
   const char *env = getenv("ABFT_COMM_ALLREDUCE");
-  if (env && strcmp(env, "board") && strcmp(env, "auto"))
+  const bool any = !env || !strcmp(env, "auto");
+  const bool want_ipc = any || !strcmp(env, "ipc"), want_host = any || !strcmp(env, "board");
+  if (!want_ipc && !want_host)
+    return;
+  // a few test sums on this very node before the board is trusted: {rank + 1 + t, 1} summed over ranks
+  auto test_sums = [&]()
+  {
+    bool all = true;
+    for (int t = 0; t < 3 && all; t++)
+    {
+      check(abft_hip_write_pair(ctx_, pair_dev_, (double)(rank + 1 + t), 1.0), "abft_hip_write_pair");
+      check(abft_hip_allreduce_pair_peers(ctx_, pair_dev_), "abft_hip_allreduce_pair_peers");
+      double v = 0.0, e = 0.0;
+      check(abft_hip_read_pair(ctx_, pair_dev_, &v, &e), "abft_hip_read_pair");
+      all = all_ranks(v == 0.5 * size * (size + 1) + (double)t * size && e == (double)size);
+    }
+    return all;
+  };
+  // First choice (round 3): the board in DEVICE memory, one copy per rank, the peers' copies mapped over
+  // IPC -- a rank pushes its slot into every copy (xGMI stores) and polls its own: no host memory in the
+  // iteration.  Taken when every rank can map every other rank's copy and the test sums come out right.
+  if (want_ipc)
+  {
+    const size_t hb = abft_hip_peer_board_ipc_handle_bytes();
+    std::vector<char> mine(hb, 0), handles(hb * (size_t)size, 0);
+    const bool exported = abft_hip_peer_board_ipc_export(ctx_, mine.data()) == ABFT_OK;
+    comm_->allgather(mine.data(), hb, handles.data());
+    bool all = all_ranks(exported);
+    const bool attached = all && abft_hip_peer_board_ipc_attach(ctx_, handles.data(), rank, size, comm_timeout_seconds()) == ABFT_OK;
+    all = all_ranks(attached);
+    if (all)
+      all = test_sums();
+    if (all)
+    {
+      peers_ok_ = true;
+      board_kind_ = "device-board";
+      if (getenv("ABFT_HIP_VERBOSE") && rank == 0)
+        fprintf(stderr, "hip backend: scalar all-reduces over the peer board in device memory (%d ranks, IPC, %s)\n", size, host);
+      return;
+    }
+    abft_hip_peer_board_detach(ctx_);  // (also frees an exported copy nobody attached)
+    if (env && !strcmp(env, "ipc"))
+    {
+      fprintf(stderr, "hip backend: ABFT_COMM_ALLREDUCE=ipc, but the device-memory board could not be set up on every rank\n");
+      exit(2);
+    }
+  }
+  if (!want_host)
     return;
   board_bytes_ = abft_hip_peer_board_bytes();
   void *map = shared_region(board_bytes_);
   const bool attached = map && abft_hip_peer_board_attach(ctx_, map, board_bytes_, rank, size, comm_timeout_seconds()) == ABFT_OK;
   bool all = all_ranks(attached);
-  for (int t = 0; t < 3 && all; t++)
-  {
-    // {rank + 1 + t, 1} summed over ranks
-    check(abft_hip_write_pair(ctx_, pair_dev_, (double)(rank + 1 + t), 1.0), "abft_hip_write_pair");
-    check(abft_hip_allreduce_pair_peers(ctx_, pair_dev_), "abft_hip_allreduce_pair_peers");
-    double v = 0.0, e = 0.0;
-    check(abft_hip_read_pair(ctx_, pair_dev_, &v, &e), "abft_hip_read_pair");
-    all = all_ranks(v == 0.5 * size * (size + 1) + (double)t * size && e == (double)size);
-  }
+  if (all)
+    all = test_sums();
   if (!all)
   {
     if (attached)
@@ -136,6 +177,7 @@ void HIPContextBase::setup_peer_board()
   }
   board_map_ = map;
   peers_ok_ = true;
+  board_kind_ = "board";
   if (getenv("ABFT_HIP_VERBOSE") && rank == 0)
     fprintf(stderr, "hip backend: scalar all-reduces over the peer board (%d ranks, %s)\n", size, host);
 }
@@ -948,7 +990,8 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     else if (const char *lr = getenv("LOCAL_RANK")) snprintf(dev_s, sizeof(dev_s), "%s", lr);
     snprintf(mine, sizeof(mine), "rank %d device %s allreduce %s exchange %s-over-%s graph %d ncclCommCount %d",
              comm_->rank(), dev_s,
-             peers_ok_ ? (fuse_allreduce_ ? "board-in-kernel-tails" : "board") : comm_->device_collectives() ? "rccl" : "tcp",
+             peers_ok_ ? (std::string(board_kind_) + (fuse_allreduce_ ? "-in-kernel-tails" : "")).c_str()
+                       : comm_->device_collectives() ? "rccl" : "tcp",
              use_windows_ ? "windows" : "allgather",
              peer_xchg_ok_ ? "board" : comm_->device_collectives() ? "rccl" : "tcp", graph ? 1 : 0, count);
     std::vector<char> all((size_t)comm_->size() * sizeof(mine));

@@ -127,6 +127,7 @@ private:
   bool replayed_[2];             // the graph of that parity has completed a replay
   void *board_map_;              // shared mapping behind the peer board (NULL: not in use)
   size_t board_bytes_;
+  const char *board_kind_;       // "device-board" (IPC-mapped device memory) or "board" (shared host memory)
   bool peers_ok_;                // every rank attached the board and it summed correctly
   bool fuse_allreduce_;          // run_fixed: the all-reduces run in the tails of the reductions themselves
   bool one_node_;                // every rank runs on this host

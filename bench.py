@@ -233,6 +233,20 @@ def single(args):
             except Exception as e:  # noqa: BLE001 -- a leg that cannot run is reported, not hidden
                 leg = {"error": repr(e)[:300], "stands_for": what}
             extras[key] = leg
+        # The loop the N > 1 lines run (host/cg-csr --bench: scalars device-resident, the iteration replayed as a
+        # hipGraph), by one process on this GPU: the like-for-like N = 1 point of the scaling curve (`value` above
+        # is the reference driver's loop, two scalars back to the host per iteration, ~9 % slower).
+        try:
+            job = cpp_job(args, args.spec, args.mode, args.fmt, False)
+            extras["config2_graph_loop"] = {
+                "workload": "cg-%s -t hip -m %s --bench %d,%d, synthetic %s, one process" % (args.fmt, args.mode, args.warmup, args.steps, args.spec),
+                "it_per_s": round(args.steps / job["seconds"], 2), "ms_per_step": round(job["seconds"] / args.steps * 1e3, 4),
+                "rr_after_last_step": job["rr"], "graph_replay": job["graph_replay"],
+                "stands_for": "N = 1 with the fixed-iteration loop that bench.py --gpus N > 1 times"}
+            if "first_attempt" in job:
+                extras["config2_graph_loop"]["first_attempt"] = job["first_attempt"]
+        except SystemExit as e:
+            extras["config2_graph_loop"] = {"error": str(e)[:300]}
 
     cpu = None
     if args.cpu_iters > 0 and args.fmt == "csr":

@@ -239,6 +239,20 @@ int abft_hip_allreduce_pair_peers(abft_hip_ctx *ctx, double *dev_pair);
  * block that finishes the shard's sum, no kernel of its own.  All ranks switch together. */
 int abft_hip_peer_board_fuse(abft_hip_ctx *ctx, int on);
 int abft_hip_peer_board_failed(abft_hip_ctx *ctx);
+/* The same board in DEVICE memory, one copy per rank: a rank pushes its slot into every copy (stores over
+ * xGMI between the GPUs of a node) and polls only its own -- no host memory, no PCIe crossing.  Across
+ * processes: every rank calls _ipc_export (allocates its copy, hands out an IPC handle of
+ * abft_hip_peer_board_ipc_handle_bytes() bytes), the handles are gathered by the caller's own means, then
+ * _ipc_attach maps the peers' copies (fails, leaving nothing attached, when a peer's memory cannot be reached:
+ * the caller then falls back to the host-memory board above).  Inside one process (two contexts standing in
+ * for two ranks): _device_alloc per rank + _attach_device with the plain pointers.  Everything else --
+ * abft_hip_allreduce_pair_peers, _fuse, _failed, _detach, identical bits on every rank -- as above. */
+size_t abft_hip_peer_board_ipc_handle_bytes(void);
+int abft_hip_peer_board_ipc_export(abft_hip_ctx *ctx, void *handle);
+int abft_hip_peer_board_ipc_attach(abft_hip_ctx *ctx, const void *handles, int rank, int size, double timeout_seconds);
+int abft_hip_peer_board_device_alloc(abft_hip_ctx *ctx, void **board);
+int abft_hip_peer_board_device_free(abft_hip_ctx *ctx, void *board);
+int abft_hip_peer_board_attach_device(abft_hip_ctx *ctx, void *const *boards, int rank, int size, double timeout_seconds);
 
 /* The windows of the gathered vector that a rank's peers read (the halo of a banded matrix)
  * exchanged between the processes of ONE node through shared host memory, in one capturable

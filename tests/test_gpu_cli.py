@@ -329,9 +329,14 @@ def test_scalar_allreduces_over_the_peer_board_equal_the_collective_layer(fmt):
     here with three processes on the one GPU; ABFT_COMM_ALLREDUCE=tcp / ABFT_COMM_EXCHANGE=tcp keep
     them on the host layer.  Both add in rank order: the same bits, iteration by iteration."""
     args = ["-f", MTX, "-t", "hip", "-m", "secded", "--flip-at", "1234:70"]
-    board = run_ranks(3, args, ("--one-gpu",), fmt=fmt)
+    board = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "board"})
     layer = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "tcp", "ABFT_COMM_EXCHANGE": "tcp"})
-    assert board.returncode == 0 and layer.returncode == 0, board.stderr[-800:] + layer.stderr[-800:]
+    # round 3, the default: the board in device memory, a copy per rank, the peers' copies mapped over IPC
+    # (between processes sharing the one GPU here; between GPUs the pushes are xGMI stores)
+    ipc = run_ranks(3, args, ("--one-gpu",), fmt=fmt)
+    assert board.returncode == 0 and layer.returncode == 0 and ipc.returncode == 0, board.stderr[-800:] + layer.stderr[-800:] + ipc.stderr[-800:]
+    assert "scalar all-reduces over the peer board in device memory (3 ranks, IPC" in ipc.stderr
+    assert hex_history(ipc.stderr) == hex_history(board.stderr)
     assert "scalar all-reduces over the peer board (3 ranks" in board.stderr
     assert board.stderr.count("exchange by windows over shared memory") == 3
     assert "peer board" not in layer.stderr and layer.stderr.count("exchange by windows over TCP") == 3
@@ -399,7 +404,7 @@ def test_bench_mode_device_scalars_and_graph_replay(spec, mode):
     t = re.findall(r"^bench_transport: (.*)$", rccl.stdout, re.M)
     assert len(t) == 1 and " allreduce rccl " in t[0] and "-over-rccl graph 1 ncclCommCount 1" in t[0], t
     t = re.findall(r"^bench_transport: (.*)$", forced.stdout, re.M)
-    assert len(t) == 1 and " allreduce board-in-kernel-tails " in t[0] and "graph 1 ncclCommCount 1" in t[0], t
+    assert len(t) == 1 and " allreduce device-board-in-kernel-tails " in t[0] and "graph 1 ncclCommCount 1" in t[0], t
     for world in (2, 3):
         many = run_ranks(world, ["-t", "hip"] + base, ("--one-gpu",))
         assert many.returncode == 0, many.stderr[-800:]

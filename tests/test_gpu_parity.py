@@ -270,11 +270,12 @@ def test_constraints_mode_in_the_sweep_layout(amd, width, rpt, lag, monkeypatch)
     cols, rows, vals, n = random_spd(120, 6, seed=8)
     x = rhs(n, 5)
     rk = set()
-    for row, mask in ((7, 1 << 30), (1, 1 << 5), (n, 1 << 29), (60, 1 << 9), (119, 1 << 31)):
+    for row, mask in ((7, 1 << 30), (7, 1 << 3), (1, 1 << 5), (n, 1 << 29), (60, 1 << 9), (119, 1 << 1), (33, 1 << 4)):
         o = OracleMatrix(CSR, "constraints", cols, rows, vals, n)
         o._view("ora_matrix_csr_rowptr", np.uint32, n + 1)[row] ^= np.uint32(mask)
         h = Hip(amd, CSR, "constraints", cols, rows, vals, n)
         try:
+            assert h.ctx.matrix_info(h.A)[0] == "sweep"
             capi.check(h.ctx.L.abft_hip_inject_rowptr(h.A.h, row, mask))
             h.spmv(x)
             o.spmv(x)

@@ -225,6 +225,93 @@ def test_all_reduce_in_the_tail_of_the_reductions(pair_of_contexts):
     assert L.abft_hip_peer_board_fuse(ctxs[0].h, 1) != 0  # not attached any more
 
 
+def attach_device_boards(L, capi, ctxs, timeout=20.0, ranks=None):
+    """the board in device memory, one copy per rank: inside one process the copies are plain pointers
+    (across processes they travel as IPC handles: test_gpu_cli.py)"""
+    size = len(ctxs)
+    boards = (C.c_void_p * size)()
+    for r, c in enumerate(ctxs):
+        p = C.c_void_p()
+        capi.check(L.abft_hip_peer_board_device_alloc(c.h, C.byref(p)))
+        boards[r] = p.value
+    for r, c in enumerate(ctxs):
+        if ranks is None or r in ranks:
+            capi.check(L.abft_hip_peer_board_attach_device(c.h, boards, r, size, timeout))
+    return boards
+
+
+def test_device_memory_board_sums_like_the_host_memory_board(pair_of_contexts):
+    """Round 3: every rank keeps a copy of the board in its own device memory, pushes its slot into every
+    copy and polls its own (between GPUs: stores over xGMI, no host memory).  Same sums, same bits on both
+    ranks, both rows of the board, inside a replayed graph, in the tails of the reductions, and a missing
+    peer is still a bounded wait with a loud result."""
+    L, capi, ctxs, pairs, addr, nbytes = pair_of_contexts
+    boards = attach_device_boards(L, capi, ctxs)
+    assert L.abft_hip_peer_board_attach_device(ctxs[0].h, boards, 0, 2, 1.0) != 0  # twice
+    rng = np.random.default_rng(5)
+    for k in range(7):
+        mine = [np.array([rng.standard_normal() * 10.0 ** rng.integers(-8, 8), float(rng.integers(0, 5))]) for _ in ctxs]
+        for c, p, m in zip(ctxs, pairs, mine):
+            c.upload(p, m)
+        for c, p in zip(ctxs, pairs):
+            capi.check(L.abft_hip_allreduce_pair_peers(c.h, p.device_ptr))
+        got = [read_pair(L, capi, c, p) for c, p in zip(ctxs, pairs)]
+        assert got[0] == got[1] == (0.0 + mine[0][0] + mine[1][0], mine[0][1] + mine[1][1]), k
+        assert not any(L.abft_hip_peer_board_failed(c.h) for c in ctxs)
+    # replayed
+    graphs = []
+    for c, p in zip(ctxs, pairs):
+        g = C.c_void_p()
+        capi.check(L.abft_hip_graph_begin(c.h))
+        capi.check(L.abft_hip_allreduce_pair_peers(c.h, p.device_ptr))
+        capi.check(L.abft_hip_graph_end(c.h, C.byref(g)))
+        graphs.append(g)
+    for c, p, m in zip(ctxs, pairs, ([1.0, 1.0], [2.5, 0.0])):
+        c.upload(p, np.array(m))
+    want = [1.0, 1.0], [2.5, 0.0]
+    for k in range(4):
+        for g in graphs:
+            capi.check(L.abft_hip_graph_launch(g))
+        got = [read_pair(L, capi, c, p) for c, p in zip(ctxs, pairs)]
+        s = (want[0][0] + want[1][0], want[0][1] + want[1][1])
+        assert got[0] == got[1] == s, k
+        want = [list(s), list(s)]
+    for g in graphs:
+        L.abft_hip_graph_destroy(g)
+    # in the tails of the reductions
+    vecs = []
+    for c, m in zip(ctxs, (70001, 1234)):
+        a, b = c.create_vector(m), c.create_vector(m)
+        c.upload(a, rng.standard_normal(m))
+        c.upload(b, rng.standard_normal(m))
+        vecs.append((a, b))
+
+    def both(fused):
+        for c in ctxs:
+            capi.check(L.abft_hip_peer_board_fuse(c.h, 1 if fused else 0))
+        for c, p, (a, b) in zip(ctxs, pairs, vecs):
+            capi.check(L.abft_hip_dot_dev(c.h, a.h, b.h, p.device_ptr))
+            if not fused:
+                capi.check(L.abft_hip_allreduce_pair_peers(c.h, p.device_ptr))
+        return [read_pair(L, capi, c, p) for c, p in zip(ctxs, pairs)]
+
+    plain, fused = both(False), both(True)
+    assert plain[0] == plain[1] and fused == plain
+    for c in ctxs:
+        capi.check(L.abft_hip_peer_board_fuse(c.h, 0))
+        capi.check(L.abft_hip_peer_board_detach(c.h))
+    # a peer that never shows up
+    capi.check(L.abft_hip_peer_board_attach_device(ctxs[0].h, boards, 0, 2, 0.5))
+    ctxs[0].upload(pairs[0], np.array([3.0, 0.0]))
+    # (the previous rounds' slots are still on the board with other sequence numbers: none fits a fresh counter)
+    capi.check(L.abft_hip_allreduce_pair_peers(ctxs[0].h, pairs[0].device_ptr))
+    v, _ = read_pair(L, capi, ctxs[0], pairs[0])
+    assert math.isnan(v) and L.abft_hip_peer_board_failed(ctxs[0].h) == 1
+    capi.check(L.abft_hip_peer_board_detach(ctxs[0].h))
+    for r, c in enumerate(ctxs):
+        capi.check(L.abft_hip_peer_board_device_free(c.h, boards[r]))
+
+
 def test_one_way_windows_wait_for_the_reader_before_reusing_an_outbox(two_ranks_with_outboxes):
     """rank 0 sends, rank 1 only receives: nothing rank 0 waits for tells it that rank 1 is through
     with an outbox, so from the third exchange on it asks (the `done` word) before overwriting one"""
