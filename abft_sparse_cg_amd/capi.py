@@ -58,6 +58,7 @@ SIGNATURES = {
                                                        C.c_int, u32p, vpp]),
     "abft_hip_matrix_destroy": (C.c_int, [vp]),
     "abft_hip_matrix_info": (C.c_int, [vp, i32p, i32p]),
+    "abft_hip_matrix_read_element": (C.c_int, [vp, C.c_uint32, u32p]),
     "abft_hip_matrix_read_csr": (C.c_int, [vp, vp, vp, vp]),
     "abft_hip_matrix_read_coo": (C.c_int, [vp, vp]),
     "abft_hip_inject": (C.c_int, [vp, C.c_uint32, i32p, C.c_int]),

@@ -1114,6 +1114,29 @@ extern "C" int abft_hip_matrix_read_coo(abft_hip_matrix *mat, void *elements) {
   return ABFT_OK;
 }
 
+// the stored words of ONE element (the caller's index): 3 for CSR {value lo, value hi, column word}, 4 for COO
+extern "C" int abft_hip_matrix_read_element(abft_hip_matrix *mat, uint32_t index, uint32_t *words) {
+  if (!mat || !words) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (int rc = bind(mat->ctx)) return rc;
+  const uint32_t nnz = mat->fmt == ABFT_FMT_CSR ? mat->csr.nnz : mat->coo.nnz;
+  if (index >= nnz) return set_err(ABFT_ERR_INVALID, "element index %u outside [0,%u)", index, nnz);
+  hipStream_t s = mat->ctx->stream;
+  const uint32_t *map = mat->fmt == ABFT_FMT_CSR ? mat->csr.pos_of_orig : mat->coo.pos_of_orig;
+  uint32_t pos = index;
+  if (map) {
+    HIPCHK(hipMemcpyAsync(&pos, map + index, sizeof(pos), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  if (mat->fmt == ABFT_FMT_CSR) {
+    HIPCHK(hipMemcpyAsync(words, mat->csr.vals + pos, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(words + 2, mat->csr.cols + pos, 4, hipMemcpyDeviceToHost, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(words, mat->coo.elems + pos, 16, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return ABFT_OK;
+}
+
 extern "C" int abft_hip_inject(abft_hip_matrix *mat, uint32_t index, const int *bits, int nbits) {
   if (!mat) return set_err(ABFT_ERR_INVALID, "null matrix");
   if (int rc = bind(mat->ctx)) return rc;

@@ -788,7 +788,43 @@ void HIPContextBase::inject_bitflip(cg_matrix *mat, BitFlipKind kind, int num_fl
     }
     if (local >= 0)
       for (int i = 0; i < num_flips; i++)
-        check(abft_hip_inject(mat->handle, (uint32_t)local, &msg[2 + i], 1), "abft_hip_inject");
+      {
+        const int bit = msg[2 + i];
+        // A shard stores the gather index re-based to the slot-padded vector.  Where no code protects the
+        // index word (none, constraints) a flipped bit must still name the column the one-process run and the
+        // reference would read -- global column ^ bit -- so it is applied in global terms: decode, flip,
+        // re-base; a column outside the matrix stays outside (n_pad + its distance past N), where the kernels
+        // read 0.0 and constraints mode raises "column size".  (The ECC modes repair the stored word itself:
+        // the plain flip is the right one there.  COO column blocks: README, "several GPUs".)
+        if (format_ == ABFT_FMT_CSR && bit >= 64 && (mode_ == ABFT_MODE_NONE || mode_ == ABFT_MODE_CONSTRAINTS))
+        {
+          uint32_t w[4] = {0, 0, 0, 0};
+          check(abft_hip_matrix_read_element(mat->handle, (uint32_t)local, w), "abft_hip_matrix_read_element");
+          const uint32_t cur = w[2];
+          const int G = comm_->size();
+          long long global;  // the column this stored word stands for
+          if (cur < (uint32_t)n_pad_ && (int)(cur % (uint32_t)slot_) < bounds_[cur / slot_ + 1] - bounds_[cur / slot_])
+            global = (long long)bounds_[cur / slot_] + cur % (uint32_t)slot_;
+          else
+            global = (long long)mat->N + ((long long)cur - n_pad_);  // already outside
+          long long flipped = global >= 0 && global <= 0xffffffffll ? (long long)((uint32_t)global ^ (1u << (bit - 64))) : global;
+          uint32_t stored;
+          if (flipped < mat->N)
+          {
+            int g = (int)(std::upper_bound(bounds_.begin(), bounds_.begin() + G + 1, (int)flipped) - bounds_.begin()) - 1;
+            stored = (uint32_t)((long long)g * slot_ + (flipped - bounds_[g]));
+          }
+          else
+            stored = (uint32_t)std::min<long long>(0xffffffffll, (long long)n_pad_ + (flipped - mat->N));
+          std::vector<int> bits;
+          for (int k = 0; k < 32; k++)
+            if (((cur ^ stored) >> k) & 1u) bits.push_back(64 + k);
+          if (!bits.empty())
+            check(abft_hip_inject(mat->handle, (uint32_t)local, bits.data(), (int)bits.size()), "abft_hip_inject");
+        }
+        else
+          check(abft_hip_inject(mat->handle, (uint32_t)local, &bit, 1), "abft_hip_inject");
+      }
     return;
   }
   int index = rand() % mat->nnz;

@@ -143,6 +143,11 @@ int abft_hip_matrix_read_csr(abft_hip_matrix *mat, uint32_t *cols, uint32_t *row
 /* COO: 16-byte elements {col,row,value} (reference COO/ecc.h:11-16), nnz of them. */
 int abft_hip_matrix_read_coo(abft_hip_matrix *mat, void *elements);
 
+/* The stored words of ONE element by the caller's index: 3 for CSR {value low, value high, column word},
+ * 4 for COO {column word, row, value low, value high} -- what inject flips bits of (a shard's host layer
+ * reads the re-based index before it flips it in global terms). */
+int abft_hip_matrix_read_element(abft_hip_matrix *mat, uint32_t index, uint32_t *words);
+
 /* reference CSR/CPUContext.cpp:135-159 / COO/CPUContext.cpp:123-140, minus the
  * rand() draws: the host picks `index` and the bits (so the libc sequence stays
  * the reference's) and the device XORs them into element `index`.  Bit
