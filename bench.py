@@ -329,10 +329,13 @@ def cpp_job(args, spec, mode, fmt, profile):
     W untimed iterations, then K timed ones bracketed by a barrier + device synchronisation on
     both sides, the slowest rank's time (CGContextExt::run_fixed).
 
-    If the job fails on ANY rank with the iteration replayed as a hipGraph (the default), ALL ranks
-    -- they agree on it, agree_codes -- repeat it once with ABFT_CG_GRAPH=0, and the failed attempt goes
-    into the output line as `first_attempt` (every rank's status, rank 0's stderr tail): an abort in the
-    replay path is then a finding in the record, never just a changed label."""
+    If the job fails on ANY rank in its default form (the iteration replayed as a hipGraph, the scalar
+    all-reduces over the peer board, halo windows through shared memory), ALL ranks -- they agree on it,
+    agree_codes -- repeat it once in the most conservative form: eager enqueue, every collective an RCCL
+    call (ABFT_CG_GRAPH=0, ABFT_COMM_ALLREDUCE=rccl, ABFT_COMM_EXCHANGE=rccl).  The failed attempt goes
+    into the output line as `first_attempt` (every rank's status, rank 0's stderr tail) and the line says
+    which form was measured: an abort in the fast path is then a finding in the record, never just a
+    changed label."""
     exe = os.path.join(ROOT, "abft_sparse_cg_amd", "host", "cg-" + fmt)
     if not os.path.exists(exe):
         raise SystemExit("%s not built (make -C abft_sparse_cg_amd/host)" % exe)
@@ -347,11 +350,12 @@ def cpp_job(args, spec, mode, fmt, profile):
     first_attempt = None
     if any(codes) and replay:
         first_attempt = {"graph_replay": True, "returncodes_by_rank": codes, "rank0_stderr_tail": p.stderr[-1500:],
+                         "second_attempt": "ABFT_CG_GRAPH=0 ABFT_COMM_ALLREDUCE=rccl ABFT_COMM_EXCHANGE=rccl",
                          "note": "status 70 = the first hipGraph replay did not finish within 180 s "
                                  "(HIPContext.cpp run_fixed); ranks that lose a peer end with other codes"}
-        sys.stderr.write("rank %s: %s failed (statuses by rank: %s); all ranks once more with ABFT_CG_GRAPH=0\n%s\n"
+        sys.stderr.write("rank %s: %s failed (statuses by rank: %s); all ranks once more, eagerly and over RCCL only\n%s\n"
                          % (rank, " ".join(cmd), codes, p.stderr[-1500:]))
-        env["ABFT_CG_GRAPH"] = "0"
+        env.update(ABFT_CG_GRAPH="0", ABFT_COMM_ALLREDUCE="rccl", ABFT_COMM_EXCHANGE="rccl")
         replay = False
         p = run_cpp(cmd, env)
         codes = agree_codes(p.returncode)

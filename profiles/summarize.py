@@ -54,5 +54,32 @@ def pmc(d, out):
             print("%-60s %-18s %14.1f  (%d launches)" % (k[:60], c, v["avg_per_launch"], v["launches"]))
 
 
+def pmc_phases(d, out, pattern, k):
+    """per-launch counters of a kernel that one SpMV launches `k` times (the panel layouts: a launch per
+    chunk of panels): dispatches matching `pattern`, in dispatch order, dealt to phase 0 .. k-1"""
+    k = int(k)
+    rows = []
+    for f in find(d, "*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if pattern in r["Kernel_Name"]:
+                rows.append((int(r["Dispatch_Id"]), r["Counter_Name"], float(r["Counter_Value"])))
+    per = defaultdict(lambda: defaultdict(float))  # dispatch -> counter -> value (summed over the CSV's rows)
+    for disp, c, v in rows:
+        per[disp][c] += v
+    acc = defaultdict(lambda: defaultdict(list))
+    for n, disp in enumerate(sorted(per)):
+        for c, v in per[disp].items():
+            acc[n % k][c].append(v)
+    res = {"phase %d" % ph: {c: {"avg_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()}
+           for ph, cs in acc.items()}
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for ph in sorted(res):
+        for c, v in res[ph].items():
+            print("%-10s %-18s %14.1f  (%d launches)" % (ph, c, v["avg_per_launch"], v["launches"]))
+
+
 if __name__ == "__main__":
-    {"trace": trace, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "pmc_phases":
+        pmc_phases(*sys.argv[2:6])
+    else:
+        {"trace": trace, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
