@@ -452,6 +452,12 @@ def main():
         print(json.dumps(out))
         return
     res = multi(args)
+    try:  # (the gloo group of agree_codes, if one was made)
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
     if res is not None:
         head, hl, xl = res
         out = dict(base)
