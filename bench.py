@@ -344,7 +344,11 @@ def cpp_job(args, spec, mode, fmt, profile):
         env["ABFT_BENCH_PROFILE"] = "1"
     cmd = [exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"]
     rank = os.environ.get("RANK", "0")
-    p = run_cpp(cmd, env)
+    first_cmd = cmd
+    if os.environ.get("ABFT_BENCH_INJECT_FAILURE") == rank:
+        # test aid (tests/test_gpu_cli.py): this rank's first attempt dies at once, as a rank with a bad device would
+        first_cmd = cmd + ["--no-such-option"]
+    p = run_cpp(first_cmd, env)
     codes = agree_codes(p.returncode)
     replay = env.get("ABFT_CG_GRAPH", "1") != "0"
     first_attempt = None
@@ -477,7 +481,7 @@ def main():
                                               "host memory, RCCL if that fails its start-up test; what each rank used: "
                                               "transport_by_rank), scalars device-resident, iteration %s" % (
                                                   args.gpus, "replayed as a hipGraph" if hl["graph_replay"] else
-                                                  "enqueued eagerly (the graph replay failed on this stack)"),
+                                                  "enqueued eagerly, every collective on the collective layer (the default form failed: first_attempt)"),
                                "rr_after_last_step": hl["rr_after_last_step"]},
                     "roofline": roof, "cpu_baseline": None,
                     # the record of an unattended run: what carried it, and that its ranks solved the same system

@@ -478,6 +478,25 @@ def test_bench_py_under_the_launcher_two_ranks_two_jobs():
         assert rec["rr_check"]["ok"] and rec["rr_check"]["rel_diff"] <= 1e-10, rec["rr_check"]
 
 
+def test_bench_py_failed_first_attempt_is_agreed_on_and_recorded():
+    """A rank whose job dies (here: rank 1's first attempt, injected) must not leave the others waiting or turn
+    into a quietly different measurement: every rank learns every rank's status (a gloo all-reduce), ALL repeat
+    the job once in the conservative form (eager, collectives on the collective layer), and the output line
+    carries the failed attempt -- statuses by rank and rank 0's stderr tail -- as `first_attempt`."""
+    env = dict(os.environ, ABFT_COMM="tcp", ABFT_HIP_DEVICE="0", ABFT_BENCH_INJECT_FAILURE="1", ABFT_COMM_TIMEOUT="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(24000 + os.getpid() % 5000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "6", "--warmup", "3", "--spec", "laplace5:150,150", "--mode", "secded", "--no-extras"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-800:] + p.stderr[-2500:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    fa = d["first_attempt"]
+    assert fa["returncodes_by_rank"][1] != 0 and fa["returncodes_by_rank"][0] != 0  # rank 0 lost its peer at the rendezvous
+    assert "rendezvous timed out" in fa["rank0_stderr_tail"] and "rccl" in fa["second_attempt"]
+    assert d["value"] > 0 and d["rr_check"]["ok"] and "enqueued eagerly" in d["config"]["parallelism"]
+    assert all(" graph 0 " in t for t in d["transport_by_rank"])
+
+
 @pytest.mark.parametrize("fmt", ["csr", "coo"])
 def test_abft_hip_gpus_starts_the_ranks_itself(fmt):
     """ABFT_HIP_GPUS=N and no launcher: the executable forks the other ranks before touching a GPU
