@@ -477,11 +477,13 @@ def main():
                                "N": hl["N"], "nnz": hl["nnz"], "format": args.fmt, "mode": args.mode,
                                "parallelism": "%d ranks (one process per GPU, C++ host over RCCL): output blocks cut by "
                                               "non-zeros, exchange of the search vector (all-gather: RCCL; halo windows: "
-                                              "shared host memory) + 2 all-reduces per iteration (peer board in shared "
-                                              "host memory, RCCL if that fails its start-up test; what each rank used: "
-                                              "transport_by_rank), scalars device-resident, iteration %s" % (
+                                              "shared host memory) + 2 all-reduces per iteration (peer board: a copy per "
+                                              "rank in IPC-mapped device memory, else in shared host memory, else RCCL -- "
+                                              "whichever passes its start-up test; what each rank used: transport_by_rank), "
+                                              "scalars device-resident, iteration %s" % (
                                                   args.gpus, "replayed as a hipGraph" if hl["graph_replay"] else
-                                                  "enqueued eagerly, every collective on the collective layer (the default form failed: first_attempt)"),
+                                                  ("enqueued eagerly, every collective on the collective layer (the default form failed: first_attempt)"
+                                                   if "first_attempt" in hl else "enqueued eagerly (ABFT_CG_GRAPH=0)")),
                                "rr_after_last_step": hl["rr_after_last_step"]},
                     "roofline": roof, "cpu_baseline": None,
                     # the record of an unattended run: what carried it, and that its ranks solved the same system
