@@ -242,6 +242,46 @@ def test_panel_layout_on_config2_matches_streaming_layout(amd, gen, monkeypatch)
         pan.close()
 
 
+def test_constraints_mode_full_size_on_the_sweep_layout(amd, gen, monkeypatch):
+    """Round 3: config 4's matrix in constraints mode now takes the sweep layout (round 2: streaming, 2.5 x slower).
+    Against the streaming layout of the same matrix: y bit for bit; an index flip that breaks the column order
+    inside a panel, one that breaks it across a panel boundary (the row's previous element sits in another
+    panel: the register-carried check) and one that leaves the vector are each reported as the streaming
+    layout -- the reference's row-by-row loop -- reports them (CSR/CPUContext.cpp:186-200)."""
+    mat = gen.generate("random:4194304,24,1")
+    cols, rows, vals, n = mat
+    x = np.random.default_rng(21).standard_normal(n)
+    # elements to corrupt: the first element of a row's second half (its predecessor is likely in another panel)
+    # and a mid-row element; bit 64 + k = bit k of the column word
+    r0 = 1234567
+    lo, hi = int(np.searchsorted(rows, r0)), int(np.searchsorted(rows, r0 + 1))
+    assert hi - lo >= 12
+    cases = [(lo + (hi - lo) // 2, 64 + 21), (lo + 3, 64 + 0), (lo + 5, 64 + 30), (hi - 1, 64 + 22)]
+    results = {}
+    for layout in ("stream", "sweep"):
+        monkeypatch.setenv("ABFT_HIP_LAYOUT", layout)
+        r = Run(amd, "csr", "constraints", mat)
+        try:
+            assert r.ctx.matrix_info(r.A)[0] == layout
+            y = r.spmv(x)
+            assert r.events == []
+            out = [y]
+            for idx, bit in cases:
+                r.ctx.inject_at(r.A, idx, [bit])
+                r.spmv(x)
+                out.append(list(r.events))
+                r.events.clear()
+                r.ctx.inject_at(r.A, idx, [bit])  # flip it back
+                assert bits_equal(r.spmv(x), y) and r.events == []
+            results[layout] = out
+        finally:
+            r.close()
+    assert bits_equal(results["stream"][0], results["sweep"][0])
+    assert results["stream"][1:] == results["sweep"][1:], (results["stream"][1:], results["sweep"][1:])
+    kinds = {ev[0][0] for ev in results["sweep"][1:] if ev}
+    assert 8 in kinds and len([ev for ev in results["sweep"][1:] if ev]) >= 3  # column-order violations among them
+
+
 def test_config4_row_partitioned_shards_equal_the_one_gpu_product(amd, gen):
     """BASELINE.json configs[3] in its stated form -- cg-csr -m secded row-partitioned over 8 ranks -- shard by
     shard on the one GPU: for ranks 0, 3 and 7 the shard is planned by the product's planner
