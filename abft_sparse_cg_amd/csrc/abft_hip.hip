@@ -424,10 +424,14 @@ struct PanelBuild {
 // in ascending order, so an output's additions then happen in the caller's order.
 // ABFT_HIP_LAYOUT=stream|panels|auto and ABFT_HIP_PANEL_WIDTH (entries) override.
 static bool plan_panels(int mode, const uint32_t *in_idx, const uint32_t *out_idx, int n_out, int n_in, int nnz,
-                        PanelBuild &pb) {
+                        PanelBuild &pb, bool constraints_ok = false) {
   const char *env = getenv("ABFT_HIP_LAYOUT");
   const bool force = env && (!strcmp(env, "panels") || !strcmp(env, "sweep"));  // (sweep: CSR only, 1-byte counts)
-  if ((env && !strcmp(env, "stream")) || mode == ABFT_MODE_CONSTRAINTS || nnz <= 0 || n_out <= 0) return false;
+  // constraints mode: COO only (its checks compare an element with its caller-order successor through a table
+  // of stored positions, whatever the layout; the CSR panel kernel has no check across a panel boundary --
+  // CSR matrices take the sweep layout in that mode)
+  if ((env && !strcmp(env, "stream")) || (mode == ABFT_MODE_CONSTRAINTS && !constraints_ok) || nnz <= 0 || n_out <= 0)
+    return false;
   uint32_t width = 1u << 18;  // 2 MB of x per panel; two panels per launch (ABFT_HIP_PANEL_CHUNK)
   if (const char *w = getenv("ABFT_HIP_PANEL_WIDTH")) width = (uint32_t)std::max(1L, atol(w));
   if (!force && (size_t)n_in * sizeof(double) <= (size_t)8 << 20) return false;
@@ -891,7 +895,7 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
   // layout: grouped by output (default), or (output group, row panel) segments when
   // the gathered vector is far larger than L2 and the row indices are scattered
   PanelBuild pb;
-  const bool panels = plan_panels(mode, rows, columns, n_out, n_in, nnz, pb);  // gather index = row, output = column
+  const bool panels = plan_panels(mode, rows, columns, n_out, n_in, nnz, pb, true);  // gather index = row, output = column
   for (int i = 0; i < nnz; i++) {
     const uint32_t p = panels ? pb.pos[i] : fill[columns[i]]++;
     elems[p] = El{columns[i], rows[i], values[i]};

@@ -1144,6 +1144,7 @@ hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P,
     hipError_t e;
     switch (mode) {
       case MODE_NONE: e = launch_coo_panels_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_CONSTRAINTS: e = launch_coo_panels_mode<MODE_CONSTRAINTS>(A, P, x, y, ev, f, grid, c0, c1, s); break;
       case MODE_SED: e = launch_coo_panels_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
       case MODE_SEC7: e = launch_coo_panels_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
       case MODE_SEC8: e = launch_coo_panels_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;

@@ -189,8 +189,18 @@ def test_double_bit_flips(amd, fmt, mode):
             h.close()
 
 
+@pytest.mark.parametrize("layout", [None, "panels"])
 @pytest.mark.parametrize("fmt", FMTS)
-def test_constraints_mode_detects_like_reference(amd, fmt):
+def test_constraints_mode_detects_like_reference(amd, fmt, layout, monkeypatch):
+    """every index-bit flip of four elements: the oracle's events and, where the flip passes the checks, its y.
+    `panels`: the COO panel layout forced onto the small matrix (round 3: constraints mode runs there too -- the
+    check reaches an element's caller-order successor through the table of stored positions, whatever the
+    layout; CSR keeps the streaming layout under this setting, its scattered-matrix form is the sweep layout:
+    test_constraints_mode_in_the_sweep_layout)"""
+    if layout:
+        monkeypatch.setenv("ABFT_HIP_LAYOUT", layout)
+        monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", "16")
+        monkeypatch.setenv("ABFT_HIP_PANEL_CHUNK", "2")
     cols, rows, vals, n = random_spd(50, 6, seed=4)
     x = rhs(n, 5)
     idx_bits = range(64, 96) if fmt == CSR else range(0, 64)
@@ -201,6 +211,7 @@ def test_constraints_mode_detects_like_reference(amd, fmt):
             o.inject(index, [bit])
             h = Hip(amd, fmt, "constraints", cols, rows, vals, n)
             try:
+                assert h.ctx.matrix_info(h.A)[0] == ("panels" if layout and fmt == COO else "stream")
                 h.ctx.inject_at(h.A, index, [bit])
                 y, want = h.spmv(x), o.spmv(x)
                 ev, fatal = h.take_events()
