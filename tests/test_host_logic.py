@@ -117,6 +117,26 @@ def test_host_collectives_of_the_cpp_multi_gpu_backend(world):
     assert out.stdout == "ok\n"  # rank 0's stdout is the job's; the other ranks' is discarded
 
 
+def test_self_launched_ranks_are_reaped_and_their_status_kept():
+    """ABFT_HIP_GPUS=N without a launcher (host/comm.cpp self_launch): the process forks the other ranks before
+    anything touches a GPU, binds the rendezvous socket once and keeps it, reaps the ranks on every exit() and
+    returns a rank's non-zero status instead of hiding it; under a profiler's preloaded library (which has
+    initialised the GPU runtime before main) it refuses to fork and says how to launch instead."""
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "abft_sparse_cg_amd", "host")
+    exe = os.path.join(host, "comm_test")
+    if not os.path.exists(exe):
+        pytest.skip("host/comm_test not built")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    ok = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(env, ABFT_HIP_GPUS="3"))
+    assert ok.returncode == 0 and ok.stdout.count("ok\n") == 3, ok.stdout + ok.stderr
+    bad = subprocess.run([exe], capture_output=True, text=True, timeout=120,
+                         env=dict(env, ABFT_HIP_GPUS="3", COMM_TEST_FAIL_RANK="2"))
+    assert bad.returncode == 3 and "a rank started by ABFT_HIP_GPUS ended with status 3" in bad.stderr, bad.stderr
+    prof = subprocess.run([exe], capture_output=True, text=True, timeout=120,
+                          env=dict(env, ABFT_HIP_GPUS="3", ROCP_TOOL_LIBRARIES="/opt/rocm/lib/librocprofiler-sdk-tool.so"))
+    assert prof.returncode == 2 and "cannot fork its ranks under a profiler" in prof.stderr and prof.stdout == ""
+
+
 def test_threshold_ambiguity_rule():
     """the stop test is flagged exactly when rr is within 1e-12 (relative) of a non-zero threshold"""
     from abft_sparse_cg_amd.context import threshold_ambiguous
