@@ -1531,8 +1531,13 @@ static int attach_table(abft_hip_ctx *ctx, void *const *boards, int rank, int si
     (void)hipFree(table);
     return set_err(ABFT_ERR_NOMEM, "peer board: table");
   }
-  HIPCHK(hipMemcpy(table, boards, (size_t)size * sizeof(PeerSlot *), hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(counter, 0, sizeof(*counter)));
+  if (hipMemcpy(table, boards, (size_t)size * sizeof(PeerSlot *), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(counter, 0, sizeof(*counter)) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(table);
+    (void)hipFree(counter);
+    return set_err(ABFT_ERR_HIP, "peer board: table upload failed");
+  }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
   ctx->peers.attached = true;

@@ -287,6 +287,8 @@ def agree_codes(code):
     import torch
     import torch.distributed as dist
     if not dist.is_initialized():
+        # (one node: the loopback interface always works, a host name that does not resolve does not)
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
         dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
     t = torch.zeros(world, dtype=torch.int64)
     t[int(os.environ.get("RANK", "0"))] = int(code)
