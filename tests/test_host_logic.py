@@ -137,6 +137,20 @@ def test_self_launched_ranks_are_reaped_and_their_status_kept():
     assert prof.returncode == 2 and "cannot fork its ranks under a profiler" in prof.stderr and prof.stdout == ""
 
 
+def test_bench_ranks_agree_on_every_ranks_exit_status():
+    """bench.py --gpus N: before deciding to repeat a failed job, every rank of the launcher learns every rank's
+    exit status (bench.agree_codes: a gloo all-reduce on the launcher's own store) -- world size 2 on the CPU."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(25000 + os.getpid() % 4000), os.path.join(root, "tests", "_agree_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0, p.stdout[-500:] + p.stderr[-1500:]
+    import re
+    got = sorted(re.findall(r"AGREE rank \d \[[^\]]*\] \[[^\]]*\]", p.stdout))  # (the two ranks' lines may run together)
+    assert got == ["AGREE rank 0 [0, 70] [-6, 0]", "AGREE rank 1 [0, 70] [-6, 0]"], p.stdout
+
+
 def test_threshold_ambiguity_rule():
     """the stop test is flagged exactly when rr is within 1e-12 (relative) of a non-zero threshold"""
     from abft_sparse_cg_amd.context import threshold_ambiguous
