@@ -105,6 +105,13 @@ SIGNATURES = {
     "abft_hip_peer_exchange_begin": (C.c_int, [vp, vp, C.c_int]),
     "abft_hip_peer_exchange_finish": (C.c_int, [vp]),
     "abft_hip_peer_exchange_failed": (C.c_int, [vp]),
+    "abft_hip_peer_exchange_ipc_export": (C.c_int, [vp, C.c_int, C.c_size_t, vp]),
+    "abft_hip_peer_exchange_ipc_attach": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_size_t, vp, C.c_int, vp, C.c_int,
+                                                    C.c_double]),
+    "abft_hip_peer_exchange_device_alloc": (C.c_int, [vp, C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "abft_hip_peer_exchange_device_free": (C.c_int, [vp, vp]),
+    "abft_hip_peer_exchange_attach_device": (C.c_int, [vp, C.POINTER(vp), C.c_int, C.c_int, C.c_size_t, vp, C.c_int, vp,
+                                                       C.c_int, C.c_double]),
     "abft_hip_matrix_panels": (C.c_int, [vp, i32p, i32p]),
     "abft_hip_spmv_dot_range_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int]),
     "abft_hip_graph_begin": (C.c_int, [vp]),

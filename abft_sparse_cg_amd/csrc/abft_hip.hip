@@ -98,7 +98,12 @@ struct abft_hip_ctx {
   } peers;
   // window exchange over shared host memory (abft_hip_peer_exchange_attach)
   struct {
-    void *host = nullptr;
+    bool attached = false;
+    void *host = nullptr;                   // host-memory transport: the caller's mapping
+    unsigned char *local = nullptr;         // device-memory transport: this rank's own region
+    unsigned char **table = nullptr;        // ... every rank's region by rank (device array)
+    bool own_local = false;                 // the own region was allocated by abft_hip_peer_exchange_ipc_export
+    std::vector<void *> opened;             // peers' regions opened over IPC
     PeerExchange *dev = nullptr;            // the description the kernel reads
     unsigned long long *counter = nullptr;  // device: sequence number of the last exchange
     int rank = 0;
@@ -1672,18 +1677,15 @@ extern "C" size_t abft_hip_peer_exchange_bytes(int size, size_t outbox_bytes) {
   return (ABFT_PEER_XHDR_BYTES + (size_t)size * 2u * peer_box_bytes(outbox_bytes) + 4095) & ~(size_t)4095;
 }
 
-extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, int rank, int size,
-                                             size_t outbox_bytes, const abft_peer_piece *out, int nout,
-                                             const abft_peer_piece *in, int nin, double timeout_seconds) {
-  if (int rc = bind(ctx, true)) return rc;
-  if (!shared || ((uintptr_t)shared & 4095u) || bytes < abft_hip_peer_exchange_bytes(size, outbox_bytes))
-    return set_err(ABFT_ERR_INVALID, "peer exchange: a page-aligned mapping of at least %zu bytes is needed",
-                   abft_hip_peer_exchange_bytes(size, outbox_bytes));
+// common part of the attach entry points: validates the windows, builds the description the kernel reads.
+// Exactly one of `alias` (device alias of the shared host mapping) / `regions` (every rank's device region) is set.
+static int exchange_attach_common(abft_hip_ctx *ctx, unsigned char *alias, void *const *regions, int rank, int size,
+                                  size_t outbox_bytes, const abft_peer_piece *out, int nout, const abft_peer_piece *in,
+                                  int nin, double timeout_seconds) {
   if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
     return set_err(ABFT_ERR_RANGE, "peer exchange: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
   if (nout < 0 || nin < 0 || nout > ABFT_PEER_MAX_PIECES || nin > ABFT_PEER_MAX_PIECES || (nout && !out) || (nin && !in))
     return set_err(ABFT_ERR_RANGE, "peer exchange: at most %d windows each way", ABFT_PEER_MAX_PIECES);
-  if (ctx->xchg.host) return set_err(ABFT_ERR_INVALID, "peer exchange: already attached");
   const size_t box = peer_box_bytes(outbox_bytes);
   size_t extent = 0;
   PeerExchange X{};
@@ -1705,26 +1707,26 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
     for (int j = 0; j < nin; j++) also_sender = also_sender || in[j].peer == out[k].peer;
     X.out[k].pad = also_sender ? 0 : 1;
   }
-  if (hipHostRegister(shared, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
-    (void)hipGetLastError();
-    return set_err(ABFT_ERR_HIP, "peer exchange: hipHostRegister of the shared mapping failed");
-  }
-  void *alias = nullptr;
   PeerExchange *dev = nullptr;
   unsigned long long *counter = nullptr;
-  if (hipHostGetDevicePointer(&alias, shared, 0) != hipSuccess || hipMalloc((void **)&dev, sizeof(X)) != hipSuccess ||
-      hipMalloc((void **)&counter, sizeof(*counter)) != hipSuccess ||
-      hipMemsetAsync(counter, 0, sizeof(*counter), ctx->stream) != hipSuccess) {
+  unsigned char **table = nullptr;
+  bool ok = hipMalloc((void **)&dev, sizeof(X)) == hipSuccess && hipMalloc((void **)&counter, sizeof(*counter)) == hipSuccess &&
+            hipMemsetAsync(counter, 0, sizeof(*counter), ctx->stream) == hipSuccess;
+  if (ok && regions)
+    ok = hipMalloc((void **)&table, (size_t)size * sizeof(void *)) == hipSuccess &&
+         hipMemcpy(table, regions, (size_t)size * sizeof(void *), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
     (void)hipGetLastError();
-    (void)hipHostUnregister(shared);
     (void)hipFree(dev);
     (void)hipFree(counter);
+    (void)hipFree(table);
     (void)hipGetLastError();
-    return set_err(ABFT_ERR_HIP, "peer exchange: no device view of the shared mapping");
+    return set_err(ABFT_ERR_HIP, "peer exchange: device allocations failed");
   }
   int khz = 0;
   if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || khz <= 0) khz = 100000;
-  X.shared = static_cast<unsigned char *>(alias);
+  X.regions = table;
+  X.shared = alias;
   X.counter = counter;
   X.timeout_ticks = (unsigned long long)((timeout_seconds > 0 ? timeout_seconds : 120.0) * 1e3 * khz);
   HIPCHK(hipMemcpyAsync(dev, &X, sizeof(X), hipMemcpyHostToDevice, ctx->stream));
@@ -1732,7 +1734,8 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
   HIPCHK(hipStreamCreateWithFlags(&ctx->xchg.side, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&ctx->xchg.fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ctx->xchg.join, hipEventDisableTiming));
-  ctx->xchg.host = shared;
+  ctx->xchg.attached = true;
+  ctx->xchg.table = table;
   ctx->xchg.dev = dev;
   ctx->xchg.counter = counter;
   ctx->xchg.rank = rank;
@@ -1740,12 +1743,140 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
   return ABFT_OK;
 }
 
+extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, size_t bytes, int rank, int size,
+                                             size_t outbox_bytes, const abft_peer_piece *out, int nout,
+                                             const abft_peer_piece *in, int nin, double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!shared || ((uintptr_t)shared & 4095u) || bytes < abft_hip_peer_exchange_bytes(size, outbox_bytes))
+    return set_err(ABFT_ERR_INVALID, "peer exchange: a page-aligned mapping of at least %zu bytes is needed",
+                   abft_hip_peer_exchange_bytes(size, outbox_bytes));
+  if (ctx->xchg.attached) return set_err(ABFT_ERR_INVALID, "peer exchange: already attached");
+  if (hipHostRegister(shared, bytes, hipHostRegisterMapped | hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return set_err(ABFT_ERR_HIP, "peer exchange: hipHostRegister of the shared mapping failed");
+  }
+  void *alias = nullptr;
+  if (hipHostGetDevicePointer(&alias, shared, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipHostUnregister(shared);
+    return set_err(ABFT_ERR_HIP, "peer exchange: no device view of the shared mapping");
+  }
+  if (int rc = exchange_attach_common(ctx, static_cast<unsigned char *>(alias), nullptr, rank, size, outbox_bytes, out, nout,
+                                      in, nin, timeout_seconds)) {
+    (void)hipHostUnregister(shared);
+    (void)hipGetLastError();
+    return rc;
+  }
+  ctx->xchg.host = shared;
+  return ABFT_OK;
+}
+
+// ---- the same exchange through DEVICE memory (round 3): a region per rank, windows pushed into the reader's ----
+
+static int region_alloc(abft_hip_ctx *ctx, size_t bytes, unsigned char **out) {
+  void *p = nullptr;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      return set_err(ABFT_ERR_NOMEM, "peer exchange: %zu bytes of device memory", bytes);
+    }
+  }
+  HIPCHK(hipMemset(p, 0, bytes));
+  HIPCHK(hipDeviceSynchronize());
+  *out = static_cast<unsigned char *>(p);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_device_alloc(abft_hip_ctx *ctx, int size, size_t outbox_bytes, void **region) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!region) return set_err(ABFT_ERR_INVALID, "null argument");
+  unsigned char *p = nullptr;
+  if (int rc = region_alloc(ctx, abft_hip_peer_exchange_bytes(size, outbox_bytes), &p)) return rc;
+  *region = p;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_device_free(abft_hip_ctx *ctx, void *region) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (region) HIPCHK(hipFree(region));
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_attach_device(abft_hip_ctx *ctx, void *const *regions, int rank, int size,
+                                                    size_t outbox_bytes, const abft_peer_piece *out, int nout,
+                                                    const abft_peer_piece *in, int nin, double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!regions || size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
+    return set_err(ABFT_ERR_INVALID, "peer exchange: bad arguments");
+  for (int r = 0; r < size; r++)
+    if (!regions[r] || ((uintptr_t)regions[r] & 255u)) return set_err(ABFT_ERR_INVALID, "peer exchange: region %d missing or misaligned", r);
+  if (ctx->xchg.attached) return set_err(ABFT_ERR_INVALID, "peer exchange: already attached");
+  if (int rc = exchange_attach_common(ctx, nullptr, regions, rank, size, outbox_bytes, out, nout, in, nin, timeout_seconds))
+    return rc;
+  ctx->xchg.local = static_cast<unsigned char *>(regions[rank]);
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_ipc_export(abft_hip_ctx *ctx, int size, size_t outbox_bytes, void *handle) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (!handle) return set_err(ABFT_ERR_INVALID, "null argument");
+  if (ctx->xchg.attached || ctx->xchg.own_local) return set_err(ABFT_ERR_INVALID, "peer exchange: already attached or exported");
+  unsigned char *p = nullptr;
+  if (int rc = region_alloc(ctx, abft_hip_peer_exchange_bytes(size, outbox_bytes), &p)) return rc;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    return set_err(ABFT_ERR_HIP, "peer exchange: hipIpcGetMemHandle failed");
+  }
+  memcpy(handle, &h, sizeof(h));
+  ctx->xchg.local = p;
+  ctx->xchg.own_local = true;
+  return ABFT_OK;
+}
+
+extern "C" int abft_hip_peer_exchange_ipc_attach(abft_hip_ctx *ctx, const void *handles, int rank, int size,
+                                                 size_t outbox_bytes, const abft_peer_piece *out, int nout,
+                                                 const abft_peer_piece *in, int nin, double timeout_seconds) {
+  if (int rc = bind(ctx, true)) return rc;
+  if (size < 1 || size > ABFT_PEER_MAX_RANKS || rank < 0 || rank >= size)
+    return set_err(ABFT_ERR_RANGE, "peer exchange: rank %d of %d (at most %d ranks)", rank, size, ABFT_PEER_MAX_RANKS);
+  if (!handles || !ctx->xchg.own_local || ctx->xchg.attached)
+    return set_err(ABFT_ERR_INVALID, "peer exchange: export this rank's region first (once)");
+  std::vector<void *> regions((size_t)size, nullptr);
+  regions[(size_t)rank] = ctx->xchg.local;
+  for (int r = 0; r < size; r++) {
+    if (r == rank) continue;
+    hipIpcMemHandle_t h;
+    memcpy(&h, static_cast<const char *>(handles) + (size_t)r * sizeof(h), sizeof(h));
+    void *p = nullptr;
+    if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      for (void *q : ctx->xchg.opened) (void)hipIpcCloseMemHandle(q);
+      ctx->xchg.opened.clear();
+      return set_err(ABFT_ERR_HIP, "peer exchange: rank %d's region cannot be mapped into this process (hipIpcOpenMemHandle)", r);
+    }
+    ctx->xchg.opened.push_back(p);
+    regions[(size_t)r] = p;
+  }
+  if (int rc = exchange_attach_common(ctx, nullptr, regions.data(), rank, size, outbox_bytes, out, nout, in, nin, timeout_seconds)) {
+    for (void *q : ctx->xchg.opened) (void)hipIpcCloseMemHandle(q);
+    ctx->xchg.opened.clear();
+    return rc;
+  }
+  return ABFT_OK;
+}
+
 extern "C" int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx) {
-  if (!ctx || !ctx->xchg.host) return ABFT_OK;
+  if (!ctx || (!ctx->xchg.attached && !ctx->xchg.own_local)) return ABFT_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->xchg.side) (void)hipStreamSynchronize(ctx->xchg.side);
-  (void)hipHostUnregister(ctx->xchg.host);
+  if (ctx->xchg.host) (void)hipHostUnregister(ctx->xchg.host);
+  for (void *q : ctx->xchg.opened) (void)hipIpcCloseMemHandle(q);
+  if (ctx->xchg.own_local) (void)hipFree(ctx->xchg.local);
+  (void)hipFree(ctx->xchg.table);
   (void)hipFree(ctx->xchg.dev);
   (void)hipFree(ctx->xchg.counter);
   if (ctx->xchg.fork) (void)hipEventDestroy(ctx->xchg.fork);
@@ -1763,7 +1894,7 @@ extern "C" int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx) {
 extern "C" int abft_hip_peer_exchange_begin(abft_hip_ctx *ctx, abft_hip_vector *full, int beside) {
   if (int rc = bind(ctx)) return rc;
   if (!full) return set_err(ABFT_ERR_INVALID, "null argument");
-  if (!ctx->xchg.host) return set_err(ABFT_ERR_INVALID, "peer exchange: not attached");
+  if (!ctx->xchg.attached) return set_err(ABFT_ERR_INVALID, "peer exchange: not attached");
   if (ctx->xchg.pending) return set_err(ABFT_ERR_INVALID, "peer exchange: the previous one was not finished");
   if (full->ctx != ctx || (size_t)full->n < ctx->xchg.extent)
     return set_err(ABFT_ERR_RANGE, "peer exchange: the windows reach %zu doubles, the vector holds %d", ctx->xchg.extent,
@@ -1793,9 +1924,19 @@ extern "C" int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full) 
 }
 
 extern "C" int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx) {
-  if (!ctx || !ctx->xchg.host) return 0;
-  const volatile uint32_t *fail = reinterpret_cast<const volatile uint32_t *>(
-      static_cast<unsigned char *>(ctx->xchg.host) + 2 * ABFT_PEER_MAX_RANKS * sizeof(unsigned long long));
+  if (!ctx || !ctx->xchg.attached) return 0;
+  const size_t off = 2 * ABFT_PEER_MAX_RANKS * sizeof(unsigned long long);
+  if (!ctx->xchg.host) {  // device-memory transport: the flag sits in this rank's own region
+    uint32_t f = 0;
+    (void)hipSetDevice(ctx->device);
+    if (hipMemcpy(&f, reinterpret_cast<const uint32_t *>(ctx->xchg.local + off) + ctx->xchg.rank, sizeof(f),
+                  hipMemcpyDeviceToHost) != hipSuccess) {
+      (void)hipGetLastError();
+      return 1;
+    }
+    return f != 0;
+  }
+  const volatile uint32_t *fail = reinterpret_cast<const volatile uint32_t *>(static_cast<unsigned char *>(ctx->xchg.host) + off);
   return fail[ctx->xchg.rank] != 0;
 }
 

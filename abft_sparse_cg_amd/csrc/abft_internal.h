@@ -337,6 +337,7 @@ struct PeerPiece {
   int pad;
 };
 struct PeerExchange {  // lives in device memory
+  unsigned char *const *regions;  // device-memory transport: every rank's region by rank (device table); else NULL
   unsigned char *shared;       // device alias of the mapping
   unsigned long long *counter; // sequence number of the last exchange
   int rank, size, nout, nin;

@@ -2462,7 +2462,14 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
   const unsigned long long seq = *X.counter + 1ull;
   const unsigned long long q = seq & 1ull;
   const unsigned long long salt = seq * 0x9E3779B97F4A7C15ull;
-  unsigned long long *ready = reinterpret_cast<unsigned long long *>(X.shared);
+  // Two transports, one protocol.  Shared host memory (X.regions == NULL): one region all ranks map; a rank
+  // copies its windows into ITS outbox there and the readers pull them.  Device memory (round 3): every rank
+  // has a region of the same layout in its own GPU's memory, the peers' regions mapped over IPC
+  // (X.regions[r]); a rank PUSHES each window into the reader's region -- into the box that stands for
+  // (this sender, parity) there -- and its `ready` / `done` words into the peers' headers; every wait
+  // and every read is then on the rank's own memory.
+  unsigned char *const local = X.regions ? X.regions[X.rank] : X.shared;
+  unsigned long long *ready = reinterpret_cast<unsigned long long *>(local);
   unsigned long long *done = ready + ABFT_PEER_MAX_RANKS;
   uint32_t *fail = reinterpret_cast<uint32_t *>(done + ABFT_PEER_MAX_RANKS);
   if (t == 0) s_bad = 0u;
@@ -2482,9 +2489,10 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
     atomicOr(&s_bad, 1u);
   __syncthreads();
   XSTAMP(1);
-  unsigned char *mybox = X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)X.rank * 2u + q) * X.box_bytes;
   for (int k = 0; k < X.nout; k++) {
     const PeerPiece pc = X.out[k];
+    unsigned char *mybox = (X.regions ? X.regions[pc.peer] : X.shared) + ABFT_PEER_XHDR_BYTES +
+                           ((size_t)X.rank * 2u + q) * X.box_bytes;
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(mybox + pc.box_off);
     const double *src = full + pc.vec_off;
     if (t < 2u) s_x[t] = 0u;
@@ -2512,14 +2520,19 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every thread: its stores have been taken
   __syncthreads();
   XSTAMP(3);
-  if (t == 0) sys_store_b64(ready + X.rank, seq);
+  if (X.regions) {  // into every reader's header (a reader with several windows is told several times: the same word)
+    if (t < (uint32_t)X.nout)
+      sys_store_b64(reinterpret_cast<unsigned long long *>(X.regions[X.out[t].peer]) + X.rank, seq);
+  } else if (t == 0) {
+    sys_store_b64(ready + X.rank, seq);
+  }
   if (t < (uint32_t)X.nin && !peer_wait_ge(ready + X.in[t].peer, seq, X.timeout_ticks)) atomicOr(&s_bad, 1u);
   __syncthreads();
   XSTAMP(4);
   for (int k = 0; k < X.nin && !s_bad; k++) {
     const PeerPiece pc = X.in[k];
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(
-        X.shared + ABFT_PEER_XHDR_BYTES + ((size_t)pc.peer * 2u + q) * X.box_bytes + pc.box_off);
+        local + ABFT_PEER_XHDR_BYTES + ((size_t)pc.peer * 2u + q) * X.box_bytes + pc.box_off);
     double *dst = full + pc.vec_off;
     // The sender stored the window, waited for those stores, then stored the sequence number this
     // rank has now seen.  The check word makes a window that is not (yet) what its sender wrote for
@@ -2585,9 +2598,12 @@ __global__ __launch_bounds__(1024) void peer_exchange_kernel(const PeerExchange 
       if (X.nin > 0) full[X.in[0].vec_off] = __longlong_as_double(0x7ff8000000000000ll);
       __hip_atomic_store(fail + X.rank, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    sys_store_b64(done + X.rank, seq);  // (every load of this block has returned: the barrier above)
+    if (!X.regions) sys_store_b64(done + X.rank, seq);  // (every load of this block has returned: the barrier above)
     *X.counter = seq;
   }
+  // device memory: "through with exchange seq" goes into the header of every rank this one reads from
+  if (X.regions && t < (uint32_t)X.nin)
+    sys_store_b64(reinterpret_cast<unsigned long long *>(X.regions[X.in[t].peer]) + ABFT_PEER_MAX_RANKS + X.rank, seq);
 }
 
 hipError_t launch_peer_exchange(const PeerExchange *X, double *full, hipStream_t s) {

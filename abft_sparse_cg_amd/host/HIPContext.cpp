@@ -19,7 +19,7 @@
 HIPContextBase::HIPContextBase(int format, int mode)
   : ctx_(NULL), format_(format), mode_(mode), comm_(Comm::from_env()), slot_(0), n_pad_(0), n_loc_(0),
     r0_(0), use_windows_(false), overlap_(false), pair_(NULL), pair_dev_(NULL), fused_vec_(NULL), fused_res_(NULL),
-    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), board_kind_("board"), peers_ok_(false), fuse_allreduce_(false),
+    fixed_scal_(NULL), fixed_scal_dev_(NULL), board_map_(NULL), board_bytes_(0), board_kind_("board"), xchg_kind_("board"), peers_ok_(false), fuse_allreduce_(false),
     one_node_(false), xchg_map_(NULL), xchg_bytes_(0), peer_xchg_ok_(false), has_interior_(false), fixed_beside_(false)
 {
   fixed_graph_[0] = fixed_graph_[1] = NULL;
@@ -192,12 +192,15 @@ void HIPContextBase::setup_peer_exchange()
   if (peer_xchg_ok_)
   {
     abft_hip_peer_exchange_detach(ctx_);
-    munmap(xchg_map_, xchg_bytes_);
+    if (xchg_map_)
+      munmap(xchg_map_, xchg_bytes_);
     xchg_map_ = NULL;
     peer_xchg_ok_ = false;
   }
   const char *env = getenv("ABFT_COMM_EXCHANGE");
-  if (env && strcmp(env, "board") && strcmp(env, "auto"))
+  const bool any = !env || !strcmp(env, "auto");
+  const bool want_ipc = any || !strcmp(env, "ipc"), want_host = any || !strcmp(env, "board");
+  if (!want_ipc && !want_host)
     return;
   const int G = comm_->size(), me = comm_->rank();
   if (!one_node_ || !use_windows_ || G < 2)
@@ -218,15 +221,9 @@ void HIPContextBase::setup_peer_exchange()
   if (const char *c = getenv("ABFT_COMM_WINDOW_BYTES")) cap = atoll(c);
   if (box == 0 || (long long)box > cap)
     return;
-  xchg_bytes_ = abft_hip_peer_exchange_bytes(G, box);
-  void *map = shared_region(xchg_bytes_);
-  const bool attached = map && abft_hip_peer_exchange_attach(ctx_, map, xchg_bytes_, me, G, box, out.empty() ? NULL : out.data(),
-                                                             (int)out.size(), in.empty() ? NULL : in.data(), (int)in.size(),
-                                                             comm_timeout_seconds()) == ABFT_OK;
-  bool all = all_ranks(attached);
-  if (all)
+  // two test exchanges (both outboxes) of a vector whose entry i of slot g holds (g + 1) * 2^26 + i + round
+  auto test_exchanges = [&]()
   {
-    // two test exchanges (both outboxes) of a vector whose entry i of slot g holds (g + 1) * 2^26 + i + round
     abft_hip_vector *probe = NULL;
     check(abft_hip_vector_create(ctx_, n_pad_, &probe), "abft_hip_vector_create");
     bool right = true;
@@ -248,8 +245,45 @@ void HIPContextBase::setup_peer_exchange()
       check(abft_hip_vector_unmap(probe, h), "abft_hip_vector_unmap");
     }
     abft_hip_vector_destroy(probe);
-    all = all_ranks(right && !abft_hip_peer_exchange_failed(ctx_));
+    return all_ranks(right && !abft_hip_peer_exchange_failed(ctx_));
+  };
+  const abft_peer_piece *po = out.empty() ? NULL : out.data(), *pi = in.empty() ? NULL : in.data();
+  // First choice (round 3): a region per rank in DEVICE memory, the peers' regions mapped over IPC; a rank pushes
+  // its windows into the reader's region (xGMI stores between GPUs) and reads only its own memory.
+  if (want_ipc)
+  {
+    const size_t hb = abft_hip_peer_board_ipc_handle_bytes();
+    std::vector<char> mine(hb, 0), handles(hb * (size_t)G, 0);
+    const bool exported = abft_hip_peer_exchange_ipc_export(ctx_, G, box, mine.data()) == ABFT_OK;
+    comm_->allgather(mine.data(), hb, handles.data());
+    bool all = all_ranks(exported);
+    const bool attached = all && abft_hip_peer_exchange_ipc_attach(ctx_, handles.data(), me, G, box, po, (int)out.size(), pi,
+                                                                   (int)in.size(), comm_timeout_seconds()) == ABFT_OK;
+    all = all_ranks(attached);
+    if (all)
+      all = test_exchanges();
+    if (all)
+    {
+      peer_xchg_ok_ = true;
+      xchg_kind_ = "device-board";
+      return;
+    }
+    abft_hip_peer_exchange_detach(ctx_);  // (also frees an exported region nobody attached)
+    if (env && !strcmp(env, "ipc"))
+    {
+      fprintf(stderr, "hip backend: ABFT_COMM_EXCHANGE=ipc, but the device-memory exchange could not be set up on every rank\n");
+      exit(2);
+    }
   }
+  if (!want_host)
+    return;
+  xchg_bytes_ = abft_hip_peer_exchange_bytes(G, box);
+  void *map = shared_region(xchg_bytes_);
+  const bool attached = map && abft_hip_peer_exchange_attach(ctx_, map, xchg_bytes_, me, G, box, po, (int)out.size(), pi,
+                                                             (int)in.size(), comm_timeout_seconds()) == ABFT_OK;
+  bool all = all_ranks(attached);
+  if (all)
+    all = test_exchanges();
   if (!all)
   {
     if (attached)
@@ -265,6 +299,7 @@ void HIPContextBase::setup_peer_exchange()
   }
   xchg_map_ = map;
   peer_xchg_ok_ = true;
+  xchg_kind_ = "board";
 }
 
 void HIPContextBase::check_peer_board()
@@ -520,7 +555,7 @@ void HIPContextBase::adopt_plan(cg_matrix *M, const ShardPlan &plan)
     fprintf(stderr, "hip backend: rank %d of %d: %s [%d,%d), %zu non-zeros from element %zu, exchange by %s over %s, "
             "interior rows [%d,%d)%s\n", me, G, format_ == ABFT_FMT_CSR ? "rows" : "columns", r0_, r0_ + n_loc_, cnt,
             plan.first, use_windows_ ? "windows" : "all-gather",
-            peer_xchg_ok_ ? "shared memory" : comm_->device_collectives() ? "RCCL" : "TCP",
+            peer_xchg_ok_ ? (xchg_map_ ? "shared memory" : "device memory (IPC)") : comm_->device_collectives() ? "RCCL" : "TCP",
             plan.interior_lo, plan.interior_hi, overlap_ ? " beside the exchange" : "");
 }
 
@@ -1029,7 +1064,7 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
              peers_ok_ ? (std::string(board_kind_) + (fuse_allreduce_ ? "-in-kernel-tails" : "")).c_str()
                        : comm_->device_collectives() ? "rccl" : "tcp",
              use_windows_ ? "windows" : "allgather",
-             peer_xchg_ok_ ? "board" : comm_->device_collectives() ? "rccl" : "tcp", graph ? 1 : 0, count);
+             peer_xchg_ok_ ? xchg_kind_ : comm_->device_collectives() ? "rccl" : "tcp", graph ? 1 : 0, count);
     std::vector<char> all((size_t)comm_->size() * sizeof(mine));
     comm_->allgather(mine, sizeof(mine), all.data());
     if (comm_->rank() == 0)

@@ -128,6 +128,7 @@ private:
   void *board_map_;              // shared mapping behind the peer board (NULL: not in use)
   size_t board_bytes_;
   const char *board_kind_;       // "device-board" (IPC-mapped device memory) or "board" (shared host memory)
+  const char *xchg_kind_;        // the same for the window exchange
   bool peers_ok_;                // every rank attached the board and it summed correctly
   bool fuse_allreduce_;          // run_fixed: the all-reduces run in the tails of the reductions themselves
   bool one_node_;                // every rank runs on this host

@@ -291,6 +291,23 @@ int abft_hip_peer_exchange(abft_hip_ctx *ctx, abft_hip_vector *full);
 int abft_hip_peer_exchange_begin(abft_hip_ctx *ctx, abft_hip_vector *full, int beside);
 int abft_hip_peer_exchange_finish(abft_hip_ctx *ctx);
 int abft_hip_peer_exchange_failed(abft_hip_ctx *ctx);
+/* The same exchange through DEVICE memory (round 3): every rank owns a region of
+ * abft_hip_peer_exchange_bytes(size, outbox_bytes) in its GPU's memory, laid out like the shared one, and a rank
+ * PUSHES each window -- and its sequence words -- into the reader's region (stores over xGMI between the GPUs of
+ * a node); all waiting and reading is on the rank's own memory.  Across processes: _ipc_export (allocates the
+ * region, hands out an IPC handle of abft_hip_peer_board_ipc_handle_bytes() bytes), the handles gathered by the
+ * caller's own means, _ipc_attach (fails, leaving nothing attached, when a peer's region cannot be mapped).
+ * Inside one process: _device_alloc per rank + _attach_device with the plain pointers.  Window lists, outbox
+ * layout, abft_hip_peer_exchange[_begin/_finish], _failed, _detach: as above. */
+int abft_hip_peer_exchange_ipc_export(abft_hip_ctx *ctx, int size, size_t outbox_bytes, void *handle);
+int abft_hip_peer_exchange_ipc_attach(abft_hip_ctx *ctx, const void *handles, int rank, int size, size_t outbox_bytes,
+                                      const abft_peer_piece *out, int nout, const abft_peer_piece *in, int nin,
+                                      double timeout_seconds);
+int abft_hip_peer_exchange_device_alloc(abft_hip_ctx *ctx, int size, size_t outbox_bytes, void **region);
+int abft_hip_peer_exchange_device_free(abft_hip_ctx *ctx, void *region);
+int abft_hip_peer_exchange_attach_device(abft_hip_ctx *ctx, void *const *regions, int rank, int size, size_t outbox_bytes,
+                                         const abft_peer_piece *out, int nout, const abft_peer_piece *in, int nin,
+                                         double timeout_seconds);
 
 /* Device-scalar forms, for loops that keep alpha and beta on the device (no host
  * round trip per iteration; the row-partitioned solver's fixed-iteration loop):

@@ -232,8 +232,8 @@ def test_cpp_driver_row_partitioned(world, opts, mode, flip):
     notes = [l for l in many.stderr.splitlines() if l.startswith("hip backend: rank")]
     assert len(notes) == world
     if world > 1:
-        # (the windows themselves: through shared host memory, one kernel per exchange)
-        assert all("exchange by windows over shared memory" in l and "interior rows [0,0)" not in l and
+        # (the windows themselves: pushed through IPC-mapped device memory, one kernel per exchange)
+        assert all("exchange by windows over device memory (IPC)" in l and "interior rows [0,0)" not in l and
                    l.endswith("beside the exchange") for l in notes)
     else:
         assert "over RCCL" in notes[0]
@@ -329,13 +329,14 @@ def test_scalar_allreduces_over_the_peer_board_equal_the_collective_layer(fmt):
     here with three processes on the one GPU; ABFT_COMM_ALLREDUCE=tcp / ABFT_COMM_EXCHANGE=tcp keep
     them on the host layer.  Both add in rank order: the same bits, iteration by iteration."""
     args = ["-f", MTX, "-t", "hip", "-m", "secded", "--flip-at", "1234:70"]
-    board = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "board"})
+    board = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "board", "ABFT_COMM_EXCHANGE": "board"})
     layer = run_ranks(3, args, ("--one-gpu",), fmt=fmt, env={"ABFT_COMM_ALLREDUCE": "tcp", "ABFT_COMM_EXCHANGE": "tcp"})
     # round 3, the default: the board in device memory, a copy per rank, the peers' copies mapped over IPC
     # (between processes sharing the one GPU here; between GPUs the pushes are xGMI stores)
     ipc = run_ranks(3, args, ("--one-gpu",), fmt=fmt)
     assert board.returncode == 0 and layer.returncode == 0 and ipc.returncode == 0, board.stderr[-800:] + layer.stderr[-800:] + ipc.stderr[-800:]
     assert "scalar all-reduces over the peer board in device memory (3 ranks, IPC" in ipc.stderr
+    assert ipc.stderr.count("exchange by windows over device memory (IPC)") == 3
     assert hex_history(ipc.stderr) == hex_history(board.stderr)
     assert "scalar all-reduces over the peer board (3 ranks" in board.stderr
     assert board.stderr.count("exchange by windows over shared memory") == 3

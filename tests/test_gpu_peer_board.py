@@ -170,6 +170,76 @@ def test_windows_travel_both_ways_round_after_round(two_ranks_with_outboxes):
         assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
 
 
+def test_windows_pushed_through_device_memory(two_ranks_with_outboxes):
+    """Round 3: the same exchange through DEVICE memory -- a region per rank, every window pushed into the
+    reader's region, every wait and read on the rank's own memory (between GPUs: xGMI stores; here the regions
+    are plain device pointers of two contexts of one process, across processes they travel as IPC handles:
+    test_gpu_cli.py).  Both ways and one way (the back-pressure word pushed to the sender), round after round,
+    and a missing peer is a bounded wait with a loud result."""
+    L, capi, ctxs, addr, nbytes, box = two_ranks_with_outboxes
+    regions = (C.c_void_p * 2)()
+    for r, c in enumerate(ctxs):
+        p = C.c_void_p()
+        capi.check(L.abft_hip_peer_exchange_device_alloc(c.h, 2, box, C.byref(p)))
+        regions[r] = p.value
+    slot = 1000
+    out = [pieces([(1, 0 * slot + 990, 10, 0)]), pieces([(0, 1 * slot + 0, 37, 0), (0, 1 * slot + 500, 1, 512)])]
+    inn = [pieces([(1, 1 * slot + 0, 37, 0), (1, 1 * slot + 500, 1, 512)]), pieces([(0, 0 * slot + 990, 10, 0)])]
+    nout, nin = [1, 2], [2, 1]
+    for r, c in enumerate(ctxs):
+        capi.check(L.abft_hip_peer_exchange_attach_device(c.h, regions, r, 2, box, out[r], nout[r], inn[r], nin[r], 20.0))
+    assert L.abft_hip_peer_exchange_attach_device(ctxs[0].h, regions, 0, 2, box, out[0], 1, inn[0], 2, 1.0) != 0  # twice
+    full = [c.create_vector(2 * slot) for c in ctxs]
+    rng = np.random.default_rng(11)
+    for k in range(6):
+        mine = [rng.standard_normal(slot) for _ in ctxs]
+        before = []
+        for r, (c, v) in enumerate(zip(ctxs, full)):
+            h = np.full(2 * slot, -7.0 - k)
+            h[r * slot:(r + 1) * slot] = mine[r]
+            c.upload(v, h)
+            before.append(h)
+        for c, v in zip(ctxs, full):
+            capi.check(L.abft_hip_peer_exchange(c.h, v.h))
+        got = [c.download(v) for c, v in zip(ctxs, full)]
+        want0, want1 = before[0].copy(), before[1].copy()
+        want0[slot:slot + 37] = mine[1][:37]
+        want0[slot + 500] = mine[1][500]
+        want1[990:1000] = mine[0][990:]
+        assert np.array_equal(got[0], want0) and np.array_equal(got[1], want1), k
+        assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
+    for c in ctxs:
+        capi.check(L.abft_hip_peer_exchange_detach(c.h))
+    # one way: rank 0 only sends, rank 1 only receives (rank 0 asks rank 1's `done` word before reusing a box)
+    n = 300
+    capi.check(L.abft_hip_peer_exchange_attach_device(ctxs[0].h, regions, 0, 2, box, pieces([(1, 5, n, 0)]), 1, pieces([]), 0, 20.0))
+    capi.check(L.abft_hip_peer_exchange_attach_device(ctxs[1].h, regions, 1, 2, box, pieces([]), 0, pieces([(0, 5, n, 0)]), 1, 20.0))
+    small = [c.create_vector(1024) for c in ctxs]
+    for k in range(6):
+        src = rng.standard_normal(1024)
+        ctxs[0].upload(small[0], src)
+        ctxs[1].upload(small[1], np.zeros(1024))
+        capi.check(L.abft_hip_peer_exchange(ctxs[0].h, small[0].h))
+        capi.check(L.abft_hip_peer_exchange(ctxs[1].h, small[1].h))
+        want = np.zeros(1024)
+        want[5:5 + n] = src[5:5 + n]
+        assert np.array_equal(ctxs[1].download(small[1]), want), k
+    assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
+    for c in ctxs:
+        capi.check(L.abft_hip_peer_exchange_detach(c.h))
+    # a peer that never shows up
+    capi.check(L.abft_hip_peer_exchange_attach_device(ctxs[0].h, regions, 0, 2, box, pieces([(1, 0, 8, 0)]), 1,
+                                                      pieces([(1, 32, 8, 0)]), 1, 0.5))
+    v = ctxs[0].create_vector(64)
+    ctxs[0].upload(v, np.arange(64.0))
+    capi.check(L.abft_hip_peer_exchange(ctxs[0].h, v.h))
+    got = ctxs[0].download(v)
+    assert math.isnan(got[32]) and L.abft_hip_peer_exchange_failed(ctxs[0].h) == 1
+    capi.check(L.abft_hip_peer_exchange_detach(ctxs[0].h))
+    for r, c in enumerate(ctxs):
+        capi.check(L.abft_hip_peer_exchange_device_free(c.h, regions[r]))
+
+
 def test_exchange_gives_up_loudly_and_refuses_bad_windows(two_ranks_with_outboxes):
     L, capi, ctxs, addr, nbytes, box = two_ranks_with_outboxes
     c = ctxs[0]
