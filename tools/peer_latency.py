@@ -39,12 +39,27 @@ def main():
     keep1, xaddr = shared(xb)
     keep2, baddr = shared(L.abft_hip_peer_board_bytes())
     full, pairs = [], []
+    # ABFT_PEER_LATENCY=device: the round-3 transports -- a board copy and an exchange region per rank in DEVICE
+    # memory (inside one process: plain pointers; across processes they travel as IPC handles)
+    device = os.environ.get("ABFT_PEER_LATENCY") == "device"
+    regions, boards = (C.c_void_p * 2)(), (C.c_void_p * 2)()
+    if device:
+        for r, c in enumerate(ctxs):
+            p = C.c_void_p()
+            capi.check(L.abft_hip_peer_exchange_device_alloc(c.h, 2, box, C.byref(p)))
+            regions[r] = p.value
+            capi.check(L.abft_hip_peer_board_device_alloc(c.h, C.byref(p)))
+            boards[r] = p.value
     for r, c in enumerate(ctxs):
         o = 1 - r
         out = (Piece * 1)(Piece(o, r * slot + (slot - win if r == 0 else 0), win, 0))
         inn = (Piece * 1)(Piece(o, o * slot + (slot - win if o == 0 else 0), win, 0))
-        capi.check(L.abft_hip_peer_exchange_attach(c.h, xaddr[r], xb, r, 2, box, out, 1, inn, 1, 20.0))
-        capi.check(L.abft_hip_peer_board_attach(c.h, baddr[r], L.abft_hip_peer_board_bytes(), r, 2, 20.0))
+        if device:
+            capi.check(L.abft_hip_peer_exchange_attach_device(c.h, regions, r, 2, box, out, 1, inn, 1, 20.0))
+            capi.check(L.abft_hip_peer_board_attach_device(c.h, boards, r, 2, 20.0))
+        else:
+            capi.check(L.abft_hip_peer_exchange_attach(c.h, xaddr[r], xb, r, 2, box, out, 1, inn, 1, 20.0))
+            capi.check(L.abft_hip_peer_board_attach(c.h, baddr[r], L.abft_hip_peer_board_bytes(), r, 2, 20.0))
         v = c.create_vector(2 * slot)
         c.upload(v, np.random.default_rng(r).random(2 * slot))
         full.append(v)
@@ -88,7 +103,8 @@ def main():
                 c.synchronize()
             dt = (time.perf_counter() - t0) / K * 1e6
             best = dt if best is None else min(best, dt)
-        print("peer_latency: %s in a graph of %d: %.2f us each (best of 5, incl. the gap between kernels)" % (what, K, best))
+        print("peer_latency (%s memory): %s in a graph of %d: %.2f us each (best of 5, incl. the gap between kernels)"
+              % ("device" if device else "host", what, K, best))
         if what == "exchange" and os.environ.get("ABFT_HIP_LIB"):  # a -DABFT_DBG_STAMPS build leaves the last exchange's phase stamps
             st = np.frombuffer(keep1[0], dtype=np.uint64, count=512)[256:256 + 16].reshape(2, 8)[:, :6].astype(np.int64)
             for r in range(2):

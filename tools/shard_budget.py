@@ -21,7 +21,7 @@ Projection per iteration at G ranks:
     T_exchange = all-gather of 8 * slot bytes per rank over xGMI: each rank receives (G-1) slots,
                  one from each peer over its own link, concurrently: 8 * slot / (LINK_GBPS * EFF)
                  (banded matrices exchange halo windows of a few KB through shared host memory
-                 instead, one kernel: T_WINDOW_US = 14, measured between two streams of one GPU
+                 instead, one kernel: T_WINDOW_US = 9 (device memory; 14 through host memory), measured between two streams of one GPU
                  with windows of config 2's size, tools/peer_latency.py)
 with LINK_GBPS = 153 (MI355X_MICROARCH.md: 7 links x ~153 GB/s), EFF = 0.7.
 Prints a markdown table (commit it under profiles/)."""
@@ -38,7 +38,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-LINK_GBPS, EFF, T_WINDOW_US = 153.0, 0.7, 14.0
+LINK_GBPS, EFF, T_WINDOW_US = 153.0, 0.7, 9.0
 
 
 def shard(spec, G, k):
@@ -80,8 +80,16 @@ def time_shard(mode, pin, lrows, vals, n_loc, n_pad, slot, k, iters=60, allreduc
 
     board = None
     if allreduce:  # a board of one rank: the all-reduce kernel's own cost
-        board = mmap.mmap(-1, L.abft_hip_peer_board_bytes())
-        capi.check(L.abft_hip_peer_board_attach(h, C.addressof(C.c_char.from_buffer(board)), len(board), 0, 1, 5.0))
+        # the board as the multi-process host sets it up first (round 3): a copy in device memory
+        # (ABFT_SHARD_BUDGET_BOARD=host: the shared-host-memory board of round 2)
+        if os.environ.get("ABFT_SHARD_BUDGET_BOARD") == "host":
+            board = mmap.mmap(-1, L.abft_hip_peer_board_bytes())
+            capi.check(L.abft_hip_peer_board_attach(h, C.addressof(C.c_char.from_buffer(board)), len(board), 0, 1, 5.0))
+        else:
+            bp = C.c_void_p()
+            capi.check(L.abft_hip_peer_board_device_alloc(h, C.byref(bp)))
+            boards = (C.c_void_p * 1)(bp.value)
+            capi.check(L.abft_hip_peer_board_attach_device(h, boards, 0, 1, 5.0))
         capi.check(L.abft_hip_peer_board_fuse(h, 1))  # in the tails of the reductions, as host/HIPContext.cpp runs them
 
     def it(parity):
