@@ -1497,14 +1497,12 @@ extern "C" int abft_hip_peer_board_attach(abft_hip_ctx *ctx, void *shared, size_
 static int board_alloc(abft_hip_ctx *ctx, PeerSlot **out) {
   void *p = nullptr;
   const size_t bytes = abft_hip_peer_board_bytes();
-  // fine-grained (coherent across devices) where the runtime offers it; the kernel's accesses carry
-  // sc0 sc1 either way
-  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+  // fine-grained device memory only: coherent across devices, never held non-coherently in an XCD's L2 (a peer's
+  // pushed slot must be what this rank's poll reads).  Where the runtime cannot give it, this transport is not
+  // offered -- the caller falls back to the board in shared host memory.
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) {
     (void)hipGetLastError();
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      return set_err(ABFT_ERR_NOMEM, "peer board: %zu bytes of device memory", bytes);
-    }
+    return set_err(ABFT_ERR_NOMEM, "peer board: %zu bytes of fine-grained device memory", bytes);
   }
   HIPCHK(hipMemset(p, 0, bytes));
   HIPCHK(hipDeviceSynchronize());
@@ -1775,12 +1773,10 @@ extern "C" int abft_hip_peer_exchange_attach(abft_hip_ctx *ctx, void *shared, si
 
 static int region_alloc(abft_hip_ctx *ctx, size_t bytes, unsigned char **out) {
   void *p = nullptr;
-  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+  // (fine-grained only, as the board: board_alloc)
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) {
     (void)hipGetLastError();
-    if (hipMalloc(&p, bytes) != hipSuccess) {
-      (void)hipGetLastError();
-      return set_err(ABFT_ERR_NOMEM, "peer exchange: %zu bytes of device memory", bytes);
-    }
+    return set_err(ABFT_ERR_NOMEM, "peer exchange: %zu bytes of fine-grained device memory", bytes);
   }
   HIPCHK(hipMemset(p, 0, bytes));
   HIPCHK(hipDeviceSynchronize());
