@@ -440,6 +440,32 @@ def test_run_benchmark_script(fmt):
         assert 0.0 < float(lo) <= float(mean) <= float(hi)
 
 
+def test_bench_py_one_gpu_line_carries_the_contract_keys():
+    """`python bench.py` at N = 1 on a small matrix: ONE JSON line with the driver's keys, `roofline` (bound, achieved,
+    peak, frac, traffic) and `cpu_baseline` (value, unit, cores, kind, sample: mean / min / max of 5 runs, one
+    core beside all), the K timed steps as 5 blocks with the median reported, and the like-for-like graph loop."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "3", "--spec",
+                        "laplace5:400,400", "--cpu-iters", "20", "--no-probe"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-500:] + p.stderr[-1500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["blocks"] == 5 and d["value_min"] <= d["value"] <= d["value_max"] and d["config"]["N"] == 160000
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["runs"] == 5 and c["min"] <= c["value"] <= c["max"]
+    assert c["one_core"]["cores"] == 1 and c["one_core"]["runs"] == 5 and "sample" in c
+    legs = d["extra_legs"]
+    assert legs["config2_graph_loop"]["it_per_s"] > 0 and legs["config2_graph_loop"]["graph_replay"] is True
+    assert legs["config4_shard1"]["layout"] == "sweep" and legs["config5"]["layout"] == "panels"
+
+
 def test_bench_py_multi_rank_path_runs_the_cpp_driver():
     """bench.py --gpus N (N > 1 under the launcher) starts host/cg-csr --bench per rank; here the
     same code path with one rank (collectives forced onto RCCL), small matrix, no extra leg."""
