@@ -66,10 +66,11 @@ struct SweepLayout {
   uint32_t *debug;         // optional (ABFT_HIP_SWEEP_DEBUG): {polls that waited, waits, workgroup exits}, never reset
 };
 
-// Slice layout (round 3): the sweep layout's successor for scattered CSR matrices.  What the sweep
-// kernel paid per (row, panel) CELL -- a count byte, a share of a prefix scan, a range test, a branch,
-// and a workgroup barrier per tile -- was as much as it paid per element (config 4: 26 panels x 16 rows
-// = 416 cells for 400 elements per thread).  Here nothing is per cell:
+// Slice layout (round 3; opt-in, ABFT_HIP_LAYOUT=slice: built to test whether the sweep kernel's bookkeeping
+// is what keeps it from the gather path's floor -- it is not, DESIGN.md section 4 "Round 3" -- and measured
+// slower).  What the sweep kernel pays per (row, panel) CELL -- a count byte, a share of a prefix scan, a
+// range test, a branch, and a workgroup barrier per tile -- is as much as it pays per element (config 4:
+// 26 panels x 16 rows = 416 cells for 400 elements per thread).  Here nothing is per cell:
 //   * rows are cut into SLICES of 2^rows_log2 consecutive rows; a slice belongs to ONE WAVE, which
 //     keeps the slice's running row sums in its own piece of LDS -- no other wave ever touches them,
 //     so the kernel has no barrier and no atomics at all;
