@@ -14,6 +14,9 @@
 #include <stdint.h>
 
 #define ABFT_COLMASK 0x00FFFFFFu
+#ifndef ABFT_CFG_BITOP3
+#define ABFT_CFG_BITOP3 1  // check-bit folds with v_bitop3_b32 (A/B: -DABFT_CFG_BITOP3=0)
+#endif
 
 enum { FMT_CSR = 0, FMT_COO = 1 };
 enum { MODE_NONE = 0, MODE_CONSTRAINTS = 1, MODE_SED = 2, MODE_SEC7 = 3, MODE_SEC8 = 4, MODE_SECDED = 5 };
@@ -54,12 +57,25 @@ __device__ __forceinline__ uint32_t popc(uint32_t x) { return (uint32_t)__builti
 template <int FMT, int P>
 __device__ __forceinline__ uint32_t ecc_fold(const uint32_t *w) {
   constexpr uint32_t m0 = ecc_mask(FMT, P, 0), m1 = ecc_mask(FMT, P, 1), m2 = ecc_mask(FMT, P, 2);
+#if ABFT_CFG_BITOP3 && defined(__HIP_DEVICE_COMPILE__)
+  // gfx950's three-input boolean op: acc ^ (word & mask) is ONE instruction (truth table 0x6c over
+  // {word, acc, mask}), so a check bit costs and + 2 x bitop3 + popcount instead of 3 and + 2 xor + popcount
+  uint32_t acc = w[0] & m0;
+  acc = __builtin_amdgcn_bitop3_b32(w[1], acc, m1, 0x6c);
+  acc = __builtin_amdgcn_bitop3_b32(w[2], acc, m2, 0x6c);
+  if (FMT == FMT_COO) {
+    constexpr uint32_t m3 = ecc_mask(FMT_COO, P, 3);
+    acc = __builtin_amdgcn_bitop3_b32(w[3], acc, m3, 0x6c);
+  }
+  return acc;
+#else
   uint32_t acc = (w[0] & m0) ^ (w[1] & m1) ^ (w[2] & m2);
   if (FMT == FMT_COO) {
     constexpr uint32_t m3 = ecc_mask(FMT_COO, P, 3);
     acc ^= w[3] & m3;
   }
   return acc;
+#endif
 }
 
 // Low bit set iff any of the 7 Hamming checks fails -- the hot-path test; the
