@@ -1277,7 +1277,10 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
   // buffer now being written, before anyone passed tile t's barrier)
   // (where 5 workgroups per CU are wanted -- every RPT but 16 -- two 16 KB buffers would not fit
   // beside each other five times: one buffer, two barriers)
-  constexpr bool TWO = (RPT == 16 || EPT <= 4) && MODE != MODE_CONSTRAINTS;  // (constraints stages the columns too: one buffer set)
+  // (constraints mode stages the columns too: one buffer set.  Measured, round 3, config 4, ms per 100 iterations
+  // against 72.5 in `none`: as is 103-104; 4 elements per thread and tile, two buffer sets, no scratch: 109;
+  // 4 rows per thread: 102; pacing lag 0 / 3: 104 / 107)
+  constexpr bool TWO = (RPT == 16 || EPT <= 4) && MODE != MODE_CONSTRAINTS;
   __shared__ __attribute__((aligned(16))) double s_buf[TWO ? 2 : 1][TILE];
   // constraints mode: the staged columns too (the checks of reference CSR/CPUContext.cpp:186-200 run in
   // the summing phase, element by element in the row's order)
@@ -1323,20 +1326,21 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
       const uint32_t o = out0 + 64u * (uint32_t)j;
       acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
     }
-    // constraints mode, per row of this thread: the column of its last element so far (a row's elements
-    // sit in several panels; the order check between the last one of a panel and the first of the next
-    // needs it), whether there is one, and whether the row has already failed a check
-    uint32_t cons_last[CONS ? RPT : 1];
-    uint32_t cons_has = 0u, cons_dead = 0u;
+    // constraints mode, per row of this thread: the column of its last element so far PLUS ONE (a row's
+    // elements sit in several panels; the order check between the last one of a panel and the first of the
+    // next needs it).  0: no element yet (every column passes `col >= 0`); ~0: the row has failed a check
+    // (no column passes `col >= ~0`, which sends every later element of the row down the cold path, where
+    // it is dropped).
+    uint32_t cons_lp1[CONS ? RPT : 1];
     if (CONS) {
 #pragma unroll
       for (int j = 0; j < RPT; j++) {
-        cons_last[j] = 0u;
+        cons_lp1[j] = 0u;
         const uint32_t row = out0 + 64u * (uint32_t)j;
         if (row < A.n_out) {  // the two row-pointer checks (reference CSR/CPUContext.cpp:173-182)
           const uint32_t rs = A.rowptr[row], re = A.rowptr[row + 1];
-          if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, row, FMT_CSR); cons_dead |= 1u << j; }
-          else if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, row, FMT_CSR); cons_dead |= 1u << j; }
+          if (re > A.nnz) { push_event(ev, ABFT_EV_ROW_SIZE, row, row, FMT_CSR); cons_lp1[j] = 0xffffffffu; }
+          else if (re < rs) { push_event(ev, ABFT_EV_ROW_ORDER, row, row, FMT_CSR); cons_lp1[j] = 0xffffffffu; }
         }
       }
     }
@@ -1440,30 +1444,32 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
               if (CONS) {
                 // the row's elements of this panel and tile, in the row's order: column inside the vector,
                 // column above its predecessor's (reference CSR/CPUContext.cpp:186-200; the predecessor of a
-                // panel's first element is the last element of the row in an earlier panel)
-                if (!((cons_dead >> j) & 1u)) {
+                // panel's first element is the last element of the row in an earlier panel).  One element is
+                // the common case and gets a straight-line path: two compares, one add.
+                uint32_t lp1 = cons_lp1[j];
+                const uint32_t c0 = s_col[a0 - b];
+                if (__builtin_expect(a1 - a0 == 1u && c0 >= lp1 && c0 < A.n_in, 1)) {
+                  t += s_prod[a0 - b];
+                  lp1 = c0 + 1u;
+                } else if (lp1 != 0xffffffffu) {
                   const uint32_t row = out0 + 64u * (uint32_t)j;
-                  uint32_t prev = cons_last[j];
-                  bool has = (cons_has >> j) & 1u;
                   for (uint32_t i = a0; i < a1; i++) {
                     const uint32_t col = s_col[i - b];
-                    if (has && col <= prev) {  // reported at the predecessor: the caller's element before this one
+                    if (col < lp1) {  // reported at the predecessor: the caller's element before this one
                       push_event(ev, ABFT_EV_COL_ORDER, event_index_of_orig(A, A.orig_index[i] - 1u), row, FMT_CSR);
-                      cons_dead |= 1u << j;
+                      lp1 = 0xffffffffu;
                       break;
                     }
                     if (col >= A.n_in) {
                       push_event(ev, ABFT_EV_COL_SIZE, event_index(A, i), row, FMT_CSR);
-                      cons_dead |= 1u << j;
+                      lp1 = 0xffffffffu;
                       break;
                     }
                     t += s_prod[i - b];
-                    prev = col;
-                    has = true;
+                    lp1 = col + 1u;
                   }
-                  cons_last[j] = prev;
-                  cons_has |= 1u << j;
                 }
+                cons_lp1[j] = lp1;
               } else {
                 csr_row_sum<MODE, ABFT_CFG_SWEEP_SHORT_SUMS>(A, ev, b, a0, a1, a1, s_prod, s_col, t);
               }
@@ -1480,7 +1486,7 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + 64u * (uint32_t)j;
-      if (o < A.n_out && !(CONS && ((cons_dead >> j) & 1u))) {  // (a row that failed a check is left alone, as in the streaming kernel)
+      if (o < A.n_out && !(CONS && cons_lp1[CONS ? j : 0] == 0xffffffffu)) {  // (a row that failed a check is left alone, as in the streaming kernel)
         y[o] = acc[j];
         if (fused) dsum += x[fuse.x_off + o] * acc[j];
       }
