@@ -1279,7 +1279,9 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
   // beside each other five times: one buffer, two barriers)
   // (constraints mode stages the columns too: one buffer set.  Measured, round 3, config 4, ms per 100 iterations
   // against 72.5 in `none`: as is 103-104; 4 elements per thread and tile, two buffer sets, no scratch: 109;
-  // 4 rows per thread: 102; pacing lag 0 / 3: 104 / 107)
+  // 4 rows per thread: 102; pacing lag 0 / 3: 104 / 107; the loop and its event sites out of line behind a
+  // straight-line path for one- and two-element cells: 117.  rocprofv3: 147 M scalar and 178 M vector
+  // instructions per SpMV against 36 M and 98 M in `none` -- the per-cell control flow, not memory.)
   constexpr bool TWO = (RPT == 16 || EPT <= 4) && MODE != MODE_CONSTRAINTS;
   __shared__ __attribute__((aligned(16))) double s_buf[TWO ? 2 : 1][TILE];
   // constraints mode: the staged columns too (the checks of reference CSR/CPUContext.cpp:186-200 run in
