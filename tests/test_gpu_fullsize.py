@@ -242,6 +242,53 @@ def test_panel_layout_on_config2_matches_streaming_layout(amd, gen, monkeypatch)
         pan.close()
 
 
+def test_largest_matrix_the_ecc_modes_admit(amd, gen):
+    """The ECC modes keep their check bits in the column's top byte (reference CSR/CPUContext.cpp:238, 282, 338,
+    404: `& 0x00FFFFFF`), so N = 2^24 is the largest matrix they can hold: the 5-point Laplacian 4096 x 4096
+    (N = 16 777 216, nnz = 83 869 696, columns up to 0xFFFFFF -- all 24 index bits set).  A.1 equals the analytic
+    row sums bit for bit in secded (CSR) and sec7 (COO); a flip in the element that carries column 0xFFFFFF and
+    one in its check byte are repaired and reported with the right index; one row more is refused loudly."""
+    nx = 4096
+    mat = gen.generate("laplace5:%d,%d" % (nx, nx))
+    cols, rows, vals, n = mat
+    nnz = len(vals)
+    assert n == 1 << 24 and nnz == 5 * n - 4 * nx and int(cols.max()) == 0xFFFFFF
+    want = laplace_row_sums(nx, nx)
+    last = nnz - 1  # (row n - 1, column n - 1): the diagonal entry with every index bit set
+    assert cols[last] == 0xFFFFFF and rows[last] == n - 1
+    for fmt, mode in (("csr", "secded"), ("coo", "sec7")):
+        r = Run(amd, fmt, mode, mat)
+        try:
+            assert bits_equal(r.spmv(np.ones(n)), want), (fmt, mode)
+            assert r.events == []
+            bits = [64 + 23, 64 + 30] if fmt == "csr" else [23, 30]  # the top index bit, a check bit
+            for b in bits:
+                r.ctx.inject_at(r.A, last, [b])
+                assert bits_equal(r.spmv(np.ones(n)), want)
+                assert r.events == [(2, last, b)], (fmt, b, r.events)
+                r.events.clear()
+            assert bits_equal(r.spmv(np.ones(n)), want) and r.events == []
+        finally:
+            r.close()
+    big = gen.generate("laplace5:%d,%d" % (nx, nx + 1))  # N = 2^24 + 4096: columns need a 25th bit
+    ctx = amd.HIPContext("secded", "csr", on_event=lambda e, f: None)
+    try:
+        with pytest.raises(amd.AbftError) as e:
+            ctx.create_matrix(big[0], big[1], big[2], big[3], len(big[2]))
+        assert e.value.code == -4 and "24 bits" in str(e.value)
+    finally:
+        ctx.close()
+    ctx = amd.HIPContext("none", "csr", on_event=lambda e, f: None)  # (no such limit without check bits)
+    try:
+        A = ctx.create_matrix(big[0], big[1], big[2], big[3], len(big[2]))
+        vx, vy = ctx.create_vector(big[3]), ctx.create_vector(big[3])
+        ctx.upload(vx, np.ones(big[3]))
+        ctx.spmv(A, vx, vy)
+        assert bits_equal(ctx.download(vy), laplace_row_sums(nx, nx + 1))
+    finally:
+        ctx.close()
+
+
 def test_constraints_mode_full_size_on_the_sweep_layout(amd, gen, monkeypatch):
     """Round 3: config 4's matrix in constraints mode now takes the sweep layout (round 2: streaming, 2.5 x slower).
     Against the streaming layout of the same matrix: y bit for bit; an index flip that breaks the column order
