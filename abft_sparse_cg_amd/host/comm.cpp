@@ -5,6 +5,7 @@
 #include <netinet/in.h>
 #include <netinet/tcp.h>
 #include <poll.h>
+#include <signal.h>
 #include <sys/socket.h>
 #include <sys/time.h>
 #include <sys/wait.h>
@@ -37,27 +38,69 @@ static int env_int(const char *name, int fallback)
 static std::vector<int> g_children;
 static int g_listen_fd = -1;  // self-launch: rank 0's rendezvous socket, bound before the fork and kept
 
-// wait for the ranks this process started; -> the first non-zero exit status among them (128 + signal)
-static int reap_children()
+// every socket this process holds towards the other ranks (rank 0: one per peer + the listening one);
+// kept here so that the exit handler below can close them: file descriptors otherwise outlive the handlers
+static std::vector<int> g_open_fds;
+
+static void forget_fd(int fd)
+{
+  for (size_t i = 0; i < g_open_fds.size(); i++)
+    if (g_open_fds[i] == fd) { g_open_fds.erase(g_open_fds.begin() + i); return; }
+}
+
+static int status_of(int status)
+{
+  return WIFEXITED(status) ? WEXITSTATUS(status) : WIFSIGNALED(status) ? 128 + WTERMSIG(status) : 1;
+}
+
+// wait for the ranks this process started, at most `limit_s` seconds; the ones still running then get
+// SIGTERM, two seconds later SIGKILL.  -> the first non-zero exit status among them (128 + signal)
+static int reap_children(int limit_s)
 {
   int worst = 0;
-  for (size_t i = 0; i < g_children.size(); i++)
+  timeval t0;
+  gettimeofday(&t0, NULL);
+  int stage = 0;  // 0: waiting, 1: SIGTERM sent, 2: SIGKILL sent
+  while (!g_children.empty())
   {
-    int status = 0;
-    if (waitpid((pid_t)g_children[i], &status, 0) < 0) continue;
-    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : WIFSIGNALED(status) ? 128 + WTERMSIG(status) : 1;
-    if (code && !worst) worst = code;
+    for (size_t i = 0; i < g_children.size();)
+    {
+      int status = 0;
+      const pid_t got = waitpid((pid_t)g_children[i], &status, WNOHANG);
+      if (got == 0) { i++; continue; }
+      if (got > 0 && status_of(status) && !worst) worst = status_of(status);
+      g_children.erase(g_children.begin() + i);  // reaped, or not ours to wait for any more
+    }
+    if (g_children.empty()) break;
+    timeval now;
+    gettimeofday(&now, NULL);
+    const double waited = (now.tv_sec - t0.tv_sec) + 1e-6 * (now.tv_usec - t0.tv_usec);
+    if (stage < 2 && waited > limit_s + 2.0 * stage)
+    {
+      for (size_t i = 0; i < g_children.size(); i++) kill((pid_t)g_children[i], stage == 0 ? SIGTERM : SIGKILL);
+      if (!worst) worst = 128 + (stage == 0 ? SIGTERM : SIGKILL);
+      stage++;
+    }
+    usleep(2000);
   }
-  g_children.clear();
   return worst;
 }
 
 // Runs on every exit() of the rank that self-launched the others (the driver's normal return, fail(),
-// the fatal-ECC exit(1), check()): the children are always reaped, and a rank that crashed or exited
-// non-zero is not hidden behind a parent that returns 0.
+// the fatal-ECC exit(1), check(), a rendezvous that timed out): the children are always reaped, and a
+// rank that crashed or exited non-zero is not hidden behind a parent that returns 0.  On a failing exit
+// the sockets are shut first -- descriptors close only after the handlers, and a child blocked in a
+// recv from this rank would otherwise never see the end of the stream while this rank waits for it --
+// and the wait is short; on a clean one the children are finishing the same program and get the
+// rendezvous' own deadline.
 static void reap_at_exit(int status, void *)
 {
-  const int worst = reap_children();
+  if (status != 0)
+  {
+    for (size_t i = 0; i < g_open_fds.size(); i++) shutdown(g_open_fds[i], SHUT_RDWR), close(g_open_fds[i]);
+    g_open_fds.clear();
+  }
+  const int worst = reap_children(status != 0 ? 5 : env_int("ABFT_COMM_TIMEOUT", 120));
   if (status == 0 && worst != 0)
   {
     fprintf(stderr, "hip backend (comm): a rank started by ABFT_HIP_GPUS ended with status %d\n", worst);
@@ -83,6 +126,7 @@ static void self_launch(int n)
   int port = 29400;
   g_listen_fd = socket(AF_INET, SOCK_STREAM, 0);
   if (g_listen_fd < 0) die("socket");
+  g_open_fds.push_back(g_listen_fd);
   {
     const int one = 1;
     setsockopt(g_listen_fd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
@@ -116,6 +160,7 @@ static void self_launch(int n)
       setenv("RANK", buf, 1);
       setenv("LOCAL_RANK", buf, 1);
       g_children.clear();
+      forget_fd(g_listen_fd);
       close(g_listen_fd);  // rank 0's
       g_listen_fd = -1;
       return;
@@ -160,9 +205,15 @@ Comm::~Comm()
     abft_rccl_destroy(rccl_);
   for (size_t i = 0; i < peers_.size(); i++)
     if (peers_[i] >= 0)
+    {
+      forget_fd(peers_[i]);
       close(peers_[i]);
+    }
   if (listen_fd_ >= 0)
+  {
+    forget_fd(listen_fd_);
     close(listen_fd_);
+  }
   // (ABFT_HIP_GPUS: the ranks this process started are reaped, and their status kept, by reap_at_exit)
 }
 
@@ -192,6 +243,7 @@ void Comm::connect_star(const char *addr, int port)
     {
       listen_fd_ = socket(AF_INET, SOCK_STREAM, 0);
       if (listen_fd_ < 0) die("socket");
+      g_open_fds.push_back(listen_fd_);
       setsockopt(listen_fd_, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));
       sockaddr_in sa;
       memset(&sa, 0, sizeof(sa));
@@ -228,6 +280,7 @@ void Comm::connect_star(const char *addr, int port)
       }
       int fd = accept(listen_fd_, NULL, NULL);
       if (fd < 0) die("accept");
+      g_open_fds.push_back(fd);
       setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
       timeval hello_to = {10, 0};  // the hello follows the connect at once
       setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &hello_to, sizeof(hello_to));
@@ -247,6 +300,7 @@ void Comm::connect_star(const char *addr, int port)
     // everyone is here: stop listening, so that a rank of a job started right behind this one
     // (bench.py runs two in a row on the same port) is refused and retries until ITS rank 0 is up,
     // instead of queueing on a socket nobody will accept from again
+    forget_fd(listen_fd_);
     close(listen_fd_);
     listen_fd_ = -1;
     return;

@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <unistd.h>
 
 #include "comm.h"
 
@@ -13,6 +14,14 @@ int main()
   Comm *c = Comm::from_env();
   if (!c) { printf("single\n"); return 0; }
   const int r = c->rank(), n = c->size();
+  // (test aid: rank 0 leaves with status 2 right after the rendezvous while the others sit in a receive
+  // from it -- the exit handler of a self-launching rank 0 must end them, not wait for them for ever)
+  if (getenv("COMM_TEST_RANK0_LEAVES") && r == 0)
+  {
+    usleep(300 * 1000);
+    fprintf(stderr, "rank 0: leaving with status 2 as asked\n");
+    exit(2);
+  }
   // bcast from every root
   for (int root = 0; root < n; root++)
   {

@@ -103,7 +103,7 @@ def test_flip_draw_ranges_follow_the_reference():
     assert bit_range("coo", "INDEX") == (0, 64)
 
 
-@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("world", [2, 5, 8])
 def test_host_collectives_of_the_cpp_multi_gpu_backend(world):
     """host/comm.cpp (TCP star through rank 0: rendezvous, bcast, all-gather(v), rank-ordered
     all-reduce) between `world` processes started by host/mgpu-run -- no GPU involved."""
@@ -135,6 +135,25 @@ def test_self_launched_ranks_are_reaped_and_their_status_kept():
     prof = subprocess.run([exe], capture_output=True, text=True, timeout=120,
                           env=dict(env, ABFT_HIP_GPUS="3", ROCP_TOOL_LIBRARIES="/opt/rocm/lib/librocprofiler-sdk-tool.so"))
     assert prof.returncode == 2 and "cannot fork its ranks under a profiler" in prof.stderr and prof.stdout == ""
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_self_launching_rank0_that_fails_ends_its_ranks_instead_of_waiting_for_them(world):
+    """Rank 0 exits non-zero (a rendezvous that timed out, check(), a fatal ECC event) while the ranks it started
+    are blocked in a receive from it: its exit handler must first shut the sockets (descriptors outlive the
+    handlers), so that the ranks see the end of the stream and leave, and bound its wait -- not hang in waitpid."""
+    import time
+    host = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "abft_sparse_cg_amd", "host")
+    exe = os.path.join(host, "comm_test")
+    if not os.path.exists(exe):
+        pytest.skip("host/comm_test not built")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    t0 = time.time()
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=60,
+                       env=dict(env, ABFT_HIP_GPUS=str(world), COMM_TEST_RANK0_LEAVES="1"))
+    assert p.returncode == 2 and time.time() - t0 < 10.0, (p.returncode, time.time() - t0, p.stderr)
+    # every other rank noticed (status 3, "lost a peer") and was reaped: nobody is left behind
+    assert p.stderr.count("lost a peer") == world - 1 and "ok" not in p.stdout, p.stderr
 
 
 def test_bench_ranks_agree_on_every_ranks_exit_status():
