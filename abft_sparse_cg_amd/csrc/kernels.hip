@@ -2646,10 +2646,27 @@ hipError_t launch_copy(double *dst, const double *src, int n, hipStream_t s) {
 
 // ------------------------------------------------------------ bandwidth probe --
 
+// (four 16-byte non-temporal loads in flight per thread, then four non-temporal stores: the plain
+// one-load-one-store grid-stride loop of rounds 1-3 reached 4.9 TB/s where the read probe reaches 6.4)
 __global__ __launch_bounds__(ABFT_BLOCK) void stream_copy_kernel(double2 *__restrict__ dst,
                                                                  const double2 *__restrict__ src, size_t n2) {
-  const size_t stride = (size_t)gridDim.x * ABFT_BLOCK;
-  for (size_t i = (size_t)blockIdx.x * ABFT_BLOCK + threadIdx.x; i < n2; i += stride) dst[i] = src[i];
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d *s = reinterpret_cast<const v2d *>(src);
+  v2d *d = reinterpret_cast<v2d *>(dst);
+  const size_t stride = (size_t)gridDim.x * ABFT_BLOCK * 4;
+  for (size_t base = (size_t)blockIdx.x * ABFT_BLOCK * 4 + threadIdx.x; base < n2; base += stride) {
+    v2d v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t i = base + (size_t)k * ABFT_BLOCK;
+      v[k] = i < n2 ? __builtin_nontemporal_load(s + i) : v2d{0.0, 0.0};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const size_t i = base + (size_t)k * ABFT_BLOCK;
+      if (i < n2) __builtin_nontemporal_store(v[k], d + i);
+    }
+  }
 }
 
 __global__ __launch_bounds__(ABFT_BLOCK) void stream_read_kernel(const double2 *__restrict__ src, size_t n2,

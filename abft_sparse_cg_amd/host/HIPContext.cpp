@@ -128,7 +128,15 @@ void HIPContextBase::setup_peer_board()
   // First choice (round 3): the board in DEVICE memory, one copy per rank, the peers' copies mapped over
   // IPC -- a rank pushes its slot into every copy (xGMI stores) and polls its own: no host memory in the
   // iteration.  Taken when every rank can map every other rank's copy and the test sums come out right.
-  if (want_ipc)
+  // (IPC handles mean something on the host that made them, and the board has 64 slots -- one_node_
+  // covers both: ranks on several hosts, or more than 64 of them, go to the collective layer)
+  const bool ipc_possible = one_node_;
+  if (want_ipc && !ipc_possible && env && !strcmp(env, "ipc"))
+  {
+    fprintf(stderr, "hip backend: ABFT_COMM_ALLREDUCE=ipc needs all %d ranks on one host (at most 64)\n", size);
+    exit(2);
+  }
+  if (want_ipc && ipc_possible)
   {
     const size_t hb = abft_hip_peer_board_ipc_handle_bytes();
     std::vector<char> mine(hb, 0), handles(hb * (size_t)size, 0);
@@ -931,7 +939,7 @@ void HIPContextBase::staged_allreduce(double *dev_pair)
 }
 
 bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w,
-                               int warmup, int steps, double *seconds, double *rr)
+                               int warmup, int steps, int blocks, double *seconds, double *rr)
 {
   fused_vec_ = fused_res_ = NULL;
   if (!fixed_scal_)
@@ -972,19 +980,21 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     fixed_beside_ = graph && comm_ && peer_xchg_ok_ && has_interior_ && env && !strcmp(env, "1");
   }
   int done = 0;
-  const int total = warmup + steps;
-  double t0 = 0.0;
-  bool timing = false;
+  if (blocks < 1) blocks = 1;
+  const int total = warmup + steps * blocks;
+  // clock reads at the start of every block and after the last one, each behind a device
+  // synchronisation + a barrier across ranks: block k runs between marks k and k + 1
+  std::vector<double> marks;
+  auto mark = [&]()
+  {
+    check(abft_hip_synchronize(ctx_), "abft_hip_synchronize");
+    if (comm_) comm_->barrier();
+    marks.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
+  };
   for (int it = 0; it < total; it++)
   {
-    if (it == warmup)
-    {
-      // the timed region: barrier + device synchronisation on both sides
-      check(abft_hip_synchronize(ctx_), "abft_hip_synchronize");
-      if (comm_) comm_->barrier();
-      t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-      timing = true;
-    }
+    if (it >= warmup && (it - warmup) % steps == 0)
+      mark();
     const int parity = it & 1;
     if (graph && it >= 2)
     {
@@ -1029,7 +1039,10 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
       fixed_iteration(A, x, r, p, w, parity);
     done++;
   }
-  check(abft_hip_synchronize(ctx_), "abft_hip_synchronize");
+  // the end of the timed region: device synchronisation + barrier, then the clock -- before any teardown
+  mark();
+  std::vector<double> dts((size_t)blocks, 0.0);
+  for (int k = 0; k < blocks; k++) dts[k] = marks[k + 1] - marks[k];
   // The graphs hold the device pointers of A, x, r, p, w, of the exchange's description and side
   // stream, and the fuse / beside decisions of THIS call: they must not outlive it (another matrix,
   // other vectors or a re-attached exchange would replay stale pointers).
@@ -1040,13 +1053,13 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     replayed_[k] = false;
   }
   if (comm_) check_peer_board();
-  if (comm_) comm_->barrier();
-  double dt = timing ? std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0 : 0.0;
   if (comm_)
   {
-    std::vector<double> all((size_t)comm_->size());
-    comm_->allgather(&dt, sizeof(dt), all.data());
-    for (size_t k = 0; k < all.size(); k++) dt = std::max(dt, all[k]);
+    // a block took as long as its slowest rank
+    std::vector<double> all((size_t)comm_->size() * blocks);
+    comm_->allgather(dts.data(), sizeof(double) * blocks, all.data());
+    for (int g = 0; g < comm_->size(); g++)
+      for (int k = 0; k < blocks; k++) dts[k] = std::max(dts[k], all[(size_t)g * blocks + k]);
   }
   double v[2] = {0.0, 0.0};
   check(abft_hip_read_pair(ctx_, fixed_scal_dev_ + 2 * (done & 1), &v[0], &v[1]), "abft_hip_read_pair");
@@ -1095,7 +1108,8 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
   fixed_beside_ = false;
   if (comm_ || v[1] > 0.0)
     report_events(true);  // collective across ranks: every rank calls it
-  if (seconds) *seconds = dt;
+  if (seconds)
+    for (int k = 0; k < blocks; k++) seconds[k] = dts[k];
   if (rr) *rr = v[0];
   return true;
 }

@@ -85,7 +85,7 @@ public:
                                         long long nnz_total, const long long *row_bounds, long long elem0,
                                         long long count);
   virtual bool run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w,
-                         int warmup, int steps, double *seconds, double *rr);
+                         int warmup, int steps, int blocks, double *seconds, double *rr);
 
 private:
   void adopt_plan(cg_matrix *M, const ShardPlan &plan);

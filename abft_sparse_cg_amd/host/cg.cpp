@@ -9,8 +9,9 @@
 // Additive options, all off by default:
 //   -s/--synthetic SPEC   build the matrix in memory (generators.cpp) instead of -f
 //   --seed N              seed for -x's rand() draws (reference: time(NULL))
-//   --flip-at I:B[,B..]   flip bit(s) B of element I -- a replayable -x
+//   --flip-at I:B[,B..]   flip bit(s) B of element I -- a replayable -x (repeatable: one element each)
 //   -q/--quiet            no per-iteration line
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -41,9 +42,9 @@ struct Options
   bool have_seed = false;
   unsigned seed = 0;
   bool quiet = false;
-  long flip_index = -1;
-  std::vector<int> flip_bits;
-  int bench_warmup = -1, bench_steps = 0;  // --bench W,K
+  struct Flip { long index; std::vector<int> bits; };
+  std::vector<Flip> flips;                 // --flip-at, in the order given (the option may be repeated)
+  int bench_warmup = -1, bench_steps = 0, bench_blocks = 1;  // --bench W,K[,B]
 };
 
 double to_double(const char *s)
@@ -94,11 +95,12 @@ void usage(const char *argv0)
          "  -s  --synthetic       SPEC  Generate the matrix in memory instead of -f:\n"
          "                              laplace5:NX,NY | random:N,K,SEED | powerlaw:N,SEED\n"
          "      --seed            N     Seed for the -x draws (default: time)\n"
-         "      --flip-at  I:B[,B...]   Flip the given bit(s) of matrix element I\n"
+         "      --flip-at  I:B[,B...]   Flip the given bit(s) of matrix element I (may be repeated)\n"
          "  -q  --quiet                 Do not print the per-iteration residual\n"
-         "      --bench  W,K            Fixed-iteration run with alpha and beta kept on the device\n"
+         "      --bench  W,K[,B]        Fixed-iteration run with alpha and beta kept on the device\n"
          "                              (the loop of -c 0 without per-iteration host round trips):\n"
-         "                              W untimed iterations, then K timed ones; prints a 'bench:' line\n");
+         "                              W untimed iterations, then B (default 1) back-to-back blocks of\n"
+         "                              K timed ones; prints a 'bench:' line with the median block\n");
   printf("\n");
 }
 
@@ -179,8 +181,9 @@ Options parse(int argc, char *argv[])
       if (++i >= argc)
         fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
       char *rest;
-      o.flip_index = strtol(argv[i], &rest, 10);
-      if (*rest != ':' || o.flip_index < 0)
+      Options::Flip f;
+      f.index = strtol(argv[i], &rest, 10);
+      if (*rest != ':' || f.index < 0)
         fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
       while (*rest == ':' || *rest == ',')
       {
@@ -188,11 +191,12 @@ Options parse(int argc, char *argv[])
         long b = strtol(rest + 1, &next, 10);
         if (next == rest + 1 || b < 0)
           fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
-        o.flip_bits.push_back((int)b);
+        f.bits.push_back((int)b);
         rest = next;
       }
       if (*rest)
         fail("Invalid --flip-at (want INDEX:BIT[,BIT...])");
+      o.flips.push_back(f);
     }
     else if (is("--quiet", "-q"))
     {
@@ -200,9 +204,9 @@ Options parse(int argc, char *argv[])
     }
     else if (is("--bench", NULL))
     {
-      if (++i >= argc || sscanf(argv[i], "%d,%d", &o.bench_warmup, &o.bench_steps) != 2 || o.bench_warmup < 0 ||
-          o.bench_steps < 1)
-        fail("Invalid --bench (want WARMUP,STEPS)");
+      if (++i >= argc || sscanf(argv[i], "%d,%d,%d", &o.bench_warmup, &o.bench_steps, &o.bench_blocks) < 2 ||
+          o.bench_warmup < 0 || o.bench_steps < 1 || o.bench_blocks < 1 || o.bench_blocks > 1000)
+        fail("Invalid --bench (want WARMUP,STEPS[,BLOCKS])");
     }
     else if (is("--help", "-h"))
     {
@@ -335,17 +339,17 @@ int main(int argc, char *argv[])
   context->unmap_vector(b, h_b);
   context->unmap_vector(x, h_x);
 
-  if (o.flip_index >= 0)
+  for (const Options::Flip &f : o.flips)
   {
     g_forced_draws.clear();
-    g_forced_draws.push_back((int)o.flip_index);
+    g_forced_draws.push_back((int)f.index);
     // rand() % width + first must give the bit: feed the bit's offset in the ANY range
-    for (int bit : o.flip_bits)
+    for (int bit : f.bits)
       g_forced_draws.push_back(bit);
     g_forced_pos = 0;
-    context->inject_bitflip(A, CGContext::ANY, (int)o.flip_bits.size());
+    context->inject_bitflip(A, CGContext::ANY, (int)f.bits.size());
   }
-  else if (o.num_bit_flips)
+  if (o.flips.empty() && o.num_bit_flips)
   {
     srand(o.have_seed ? o.seed : (unsigned)time(NULL));
     context->inject_bitflip(A, o.bitflip_kind, o.num_bit_flips);
@@ -355,11 +359,20 @@ int main(int argc, char *argv[])
   {
     // --bench: the fixed-iteration loop with device-resident scalars (CGContextExt::run_fixed)
     CGContextExt *ext = dynamic_cast<CGContextExt *>(context);
-    double seconds = 0.0, rr_last = 0.0;
-    if (!ext || !ext->run_fixed(A, b, x, r, p, w, o.bench_warmup, o.bench_steps, &seconds, &rr_last))
+    double rr_last = 0.0;
+    std::vector<double> block_seconds((size_t)o.bench_blocks, 0.0);
+    if (!ext || !ext->run_fixed(A, b, x, r, p, w, o.bench_warmup, o.bench_steps, o.bench_blocks, block_seconds.data(), &rr_last))
       fail("--bench is not supported by this implementation");
+    // the K timed steps run as B back-to-back blocks, each between two synchronisations (+ barriers);
+    // the line reports the median block (with B = 1: the block), the blocks themselves follow
+    std::vector<double> sorted(block_seconds);
+    std::sort(sorted.begin(), sorted.end());
+    const double seconds = sorted[sorted.size() / 2];
     printf("bench: ranks %d warmup %d steps %d seconds %.9f iterations_per_second %.3f rr %a\n", ext->ext_size(),
            o.bench_warmup, o.bench_steps, seconds, o.bench_steps / seconds, rr_last);
+    printf("bench_blocks: blocks %d iterations_run %d seconds", o.bench_blocks, o.bench_warmup + o.bench_blocks * o.bench_steps);
+    for (double t : block_seconds) printf(" %.9f", t);
+    printf("\n");
     context->destroy_matrix(A);
     context->destroy_vector(b);
     context->destroy_vector(x);

@@ -10,8 +10,13 @@ two scalars returned to the host.  The workload is BASELINE.json configs[1]:
 `cg-csr -t hip -m none` on the synthetic 5-point Laplacian 3162 x 3162
 (N = 9,998,244, nnz = 49,978,572), b = uniform(0,1), x0 = 0, fixed iteration
 count (-c 0).  For N > 1 the same matrix is row-partitioned over the ranks
-(strong scaling): each rank builds its own shard, the search-vector exchange and
-the two all-reduces go through torch.distributed (RCCL).
+(strong scaling): every rank of the launcher starts the C++ driver (host/cg-csr
+--bench W,K,5: one process per GPU, HIPContext.cpp + comm*.cpp); each builds its
+own shard, the search-vector exchange is an RCCL all-gather (halo windows of a
+banded matrix: pushed through IPC-mapped device memory), the two scalar
+all-reduces go over the peer board or RCCL (what each rank used is recorded in
+`transport_by_rank`).  torch.distributed is only the launcher, plus one gloo
+all-reduce of the ranks' exit codes.
 
 Rank 0 prints ONE JSON line; see the keys at the bottom.  The matrix, vectors and
 the CPU baseline are built outside the timed region; inputs are resident in HBM
@@ -205,17 +210,17 @@ def single(args):
             workload = "%s/%s/%s" % (args.spec, args.fmt, args.mode)
             roof = {"bound": "hbm", "kernel": "spmv_%s_kernel<%s>" % (args.fmt, args.mode), "achieved": ach,
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic_from_profile(workload), "avg_launch_us": kernels["spmv"]["avg_us"],
-                    "algorithmic_bytes_per_launch": byts["spmv"]}
+                    "traffic": traffic_from_profile(workload),
+                    # (traffic is NOT measured by this run: HBM bytes per launch from separate rocprofv3 --pmc passes)
+                    "traffic_source": "profiles/pmc_summary.json (committed; profiles/collect_r04.sh regenerates it)",
+                    "avg_launch_us": kernels["spmv"]["avg_us"], "algorithmic_bytes_per_launch": byts["spmv"]}
     probe = None
     if args.probe:
         c, rd = ctx.stream_probe(1 << 30, 10)
         probe = {"copy_GBps": round(c, 1), "read_GBps": round(rd, 1)}
         if roof:
-            # measured denominators beside the 8 TB/s spec: a streaming copy (reads + writes)
-            # and a streaming read of 1 GiB on this box; SpMV is ~90 % reads
-            roof["measured_copy_peak"] = probe["copy_GBps"]
-            roof["frac_of_measured_copy"] = round(roof["achieved"] / c, 4)
+            # a measured denominator beside the 8 TB/s spec: a streaming read of 1 GiB on this box (the
+            # SpMV is ~90 % reads; the copy probe's figure rides along in stream_probe, no fraction taken on it)
             roof["measured_read_peak"] = probe["read_GBps"]
             roof["frac_of_measured_read"] = round(roof["achieved"] / rd, 4)
     rr_final = state["rr"]
@@ -236,17 +241,23 @@ def single(args):
         # The loop the N > 1 lines run (host/cg-csr --bench: scalars device-resident, the iteration replayed as a
         # hipGraph), by one process on this GPU: the like-for-like N = 1 point of the scaling curve (`value` above
         # is the reference driver's loop, two scalars back to the host per iteration, ~9 % slower).
-        try:
-            job = cpp_job(args, args.spec, args.mode, args.fmt, False)
-            extras["config2_graph_loop"] = {
-                "workload": "cg-%s -t hip -m %s --bench %d,%d, synthetic %s, one process" % (args.fmt, args.mode, args.warmup, args.steps, args.spec),
-                "it_per_s": round(args.steps / job["seconds"], 2), "ms_per_step": round(job["seconds"] / args.steps * 1e3, 4),
-                "rr_after_last_step": job["rr"], "graph_replay": job["graph_replay"],
-                "stands_for": "N = 1 with the fixed-iteration loop that bench.py --gpus N > 1 times"}
-            if "first_attempt" in job:
-                extras["config2_graph_loop"]["first_attempt"] = job["first_attempt"]
-        except SystemExit as e:
-            extras["config2_graph_loop"] = {"error": str(e)[:300]}
+        graph_legs = [("config2_graph_loop", args.spec, args.fmt, args.mode,
+                       "N = 1 with the fixed-iteration loop that bench.py --gpus N > 1 times as `value`"),
+                      ("config4_graph_loop", os.environ.get("ABFT_BENCH_EXTRA_SPEC", "random:4194304,24,1"), "csr", "secded",
+                       "N = 1 base of extra_legs.config4 of the --gpus N > 1 lines (BASELINE.json configs[3], the matrix "
+                       "north_star's 6x target is quoted on): same loop, one process")]
+        for key, spec, fmt, mode, what in graph_legs:
+            try:
+                job = cpp_job(args, spec, mode, fmt, False)
+                leg = {"workload": "cg-%s -t hip -m %s --bench %d,%d,%d, synthetic %s, one process"
+                                   % (fmt, mode, args.warmup, args.steps, BLOCKS, spec)}
+                leg.update(block_stats(job, args.steps))
+                leg.update({"N": job["N"], "nnz": job["nnz"], "graph_replay": job["graph_replay"], "stands_for": what})
+                if "first_attempt" in job:
+                    leg["first_attempt"] = job["first_attempt"]
+                extras[key] = leg
+            except SystemExit as e:
+                extras[key] = {"error": str(e)[:300], "stands_for": what}
 
     cpu = None
     if args.cpu_iters > 0 and args.fmt == "csr":
@@ -309,6 +320,10 @@ def parse_cpp(p):
                   p.stdout, re.M)
     if m:
         out.update(ranks=int(m.group(1)), seconds=float(m.group(4)), rr=float.fromhex(m.group(6)))
+        # the K timed steps ran as B back-to-back blocks; `seconds` above is the median block
+        bl = re.search(r"^bench_blocks: blocks (\d+) iterations_run (\d+) seconds((?: [0-9.]+)+)$", p.stdout, re.M)
+        if bl:
+            out.update(block_seconds=[float(t) for t in bl.group(3).split()], iterations_run=int(bl.group(2)))
         h = re.search(r"^matrix size +=\s+(\d+) x", p.stdout, re.M)
         z = re.search(r"^number of non-zeros +=\s+(\d+) ", p.stdout, re.M)
         out.update(N=int(h.group(1)), nnz=int(z.group(1)))
@@ -344,7 +359,7 @@ def cpp_job(args, spec, mode, fmt, profile):
     env = dict(os.environ)
     if profile:
         env["ABFT_BENCH_PROFILE"] = "1"
-    cmd = [exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"]
+    cmd = [exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d,%d" % (args.warmup, args.steps, BLOCKS), "-q"]
     rank = os.environ.get("RANK", "0")
     first_cmd = cmd
     if os.environ.get("ABFT_BENCH_INJECT_FAILURE") == rank:
@@ -383,10 +398,19 @@ def one_rank_rr(args, spec, mode, fmt):
            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ABFT_COMM_FORCE", "ABFT_HIP_GPUS", "ABFT_BENCH_PROFILE",
                         "TORCHELASTIC_USE_AGENT_STORE")}
     env.setdefault("ABFT_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0"))
-    p = run_cpp([exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d" % (args.warmup, args.steps), "-q"], env)
+    p = run_cpp([exe, "-t", "hip", "-m", mode, "-s", spec, "--bench", "%d,%d,%d" % (args.warmup, args.steps, BLOCKS), "-q"], env)
     if p.returncode != 0:
         return {"error": "one-rank run exited with status %d: %s" % (p.returncode, p.stderr[-600:])}
     return parse_cpp(p)
+
+
+def block_stats(job, steps):
+    """median / slowest / fastest block of a cg-* --bench W,K,B job -> keys for the bench line"""
+    bs = job.get("block_seconds") or [job["seconds"]]
+    return {"it_per_s": round(steps / job["seconds"], 2), "ms_per_step": round(job["seconds"] / steps * 1e3, 4),
+            "blocks": len(bs), "it_per_s_min": round(steps / max(bs), 2), "it_per_s_max": round(steps / min(bs), 2),
+            "value_is": "median of %d back-to-back blocks of %d timed steps" % (len(bs), steps),
+            "iterations_run": job.get("iterations_run"), "rr_after_last_step": job["rr"]}
 
 
 EXTRA_SPEC_MULTI = os.environ.get("ABFT_BENCH_EXTRA_SPEC", "random:4194304,24,1")  # (override: tests)
@@ -406,10 +430,9 @@ def multi(args):
         return None
 
     def leg(job, spec, fmt, mode):
-        d = {"N": job["N"], "nnz": job["nnz"], "graph_replay": job["graph_replay"],
-             "it_per_s": round(args.steps / job["seconds"], 2),
-             "ms_per_step": round(job["seconds"] / args.steps * 1e3, 4), "rr_after_last_step": job["rr"],
-             "transport_by_rank": job.get("transport", [])}
+        d = {"N": job["N"], "nnz": job["nnz"], "graph_replay": job["graph_replay"]}
+        d.update(block_stats(job, args.steps))
+        d["transport_by_rank"] = job.get("transport", [])
         if "first_attempt" in job:
             d["first_attempt"] = job["first_attempt"]
         if world > 1 and os.environ.get("ABFT_BENCH_RR_CHECK", "1") != "0":
@@ -449,7 +472,9 @@ def main():
                     "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec)
                                if args.fmt == "csr" else "cg-coo -t hip -m %s, synthetic %s" % (args.mode, args.spec),
                                "N": n, "nnz": nnz, "format": args.fmt, "mode": args.mode, "parallelism": "1 GPU",
-                               "rr_after_last_step": rr},
+                               "rr_after_last_step": rr,
+                               # rr is the residual after ALL of these (warm-up + every block), not after K steps
+                               "iterations_run": args.warmup + len(block_dt) * args.steps},
                     "roofline": roof, "cpu_baseline": cpu, "kernels": kernels})
         if probe:
             out["stream_probe"] = probe
@@ -474,7 +499,8 @@ def main():
                     % (args.fmt, args.mode), "achieved": sp["achieved"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": sp["frac"], "traffic": None, "avg_launch_us": sp["avg_spmv_us"],
                     "algorithmic_bytes_per_launch": sp["algorithmic_bytes_per_spmv"]}
-        out.update({"value": hl["it_per_s"], "ms_per_step": hl["ms_per_step"],
+        out.update({"value": hl["it_per_s"], "ms_per_step": hl["ms_per_step"], "blocks": hl["blocks"],
+                    "value_min": hl["it_per_s_min"], "value_max": hl["it_per_s_max"], "value_is": hl["value_is"],
                     "config": {"workload": "cg-%s -t hip -m %s, synthetic %s" % (args.fmt, args.mode, args.spec),
                                "N": hl["N"], "nnz": hl["nnz"], "format": args.fmt, "mode": args.mode,
                                "parallelism": "%d ranks (one process per GPU, C++ host over RCCL): output blocks cut by "
@@ -486,7 +512,7 @@ def main():
                                                   args.gpus, "replayed as a hipGraph" if hl["graph_replay"] else
                                                   ("enqueued eagerly, every collective on the collective layer (the default form failed: first_attempt)"
                                                    if "first_attempt" in hl else "enqueued eagerly (ABFT_CG_GRAPH=0)")),
-                               "rr_after_last_step": hl["rr_after_last_step"]},
+                               "rr_after_last_step": hl["rr_after_last_step"], "iterations_run": hl["iterations_run"]},
                     "roofline": roof, "cpu_baseline": None,
                     # the record of an unattended run: what carried it, and that its ranks solved the same system
                     "transport_by_rank": hl["transport_by_rank"], "rr_check": hl.get("rr_check")})

@@ -16,7 +16,7 @@ import ctypes
 import numpy as np
 import pytest
 
-from _oracle import CSR, OracleMatrix
+from _oracle import COO, CSR, OracleMatrix
 
 pytestmark = pytest.mark.gpu
 
@@ -181,10 +181,21 @@ def test_config4_random_csr_secded_full_size(amd, gen):
                 acc += vals[k] * x[cols[k]]
             assert y[row] == acc
         assert bits_equal(r.spmv(0.5 * x), 0.5 * y)
+        # the whole vector against the oracle (reference CSR/CPUContext.cpp:353-411, OpenMP over rows), bit for bit
+        o = OracleMatrix(CSR, "secded", cols, rows, vals, n)
+        assert bits_equal(y, o.spmv(x, threads=8))
         r.ctx.inject_at(r.A, len(vals) - 1, [90])
         r.ctx.inject_at(r.A, 50000000, [11])
-        assert bits_equal(r.spmv(x), y)
-        assert sorted(r.events) == [(2, 50000000, 11), (2, len(vals) - 1, 90)]
+        o.inject(len(vals) - 1, [90])
+        o.inject(50000000, [11])
+        y_hit = r.spmv(x)
+        assert bits_equal(y_hit, y) and bits_equal(y_hit, o.spmv(x, threads=8))
+        ev_o, fatal_o = o.events()
+        assert sorted(r.events) == sorted(ev_o) == [(2, 50000000, 11), (2, len(vals) - 1, 90)] and not fatal_o
+        # both repaired in place: a second pass reports nothing, on either side
+        assert bits_equal(r.spmv(x), y) and len(r.events) == 2
+        assert bits_equal(o.spmv(x, threads=8), y) and o.events()[0] == []
+        o.close()
     finally:
         r.close()
     c = Run(amd, "coo", "secded", mat)
@@ -209,8 +220,20 @@ def test_config5_powerlaw_coo_sec7_full_size(amd, gen):
             for j in range(lo, hi):
                 acc += vals[j] * x[cols[j]]
             assert y[row] == acc
+        # the whole vector against the oracle's serial scatter (reference COO/CPUContext.cpp:250-290), bit for bit
+        o = OracleMatrix(COO, "sec7", cols, rows, vals, n)
+        assert bits_equal(y, o.spmv(x))
         c.ctx.inject_at(c.A, 1000003, [100])
-        assert bits_equal(c.spmv(x), y) and c.events == [(2, 1000003, 100)]
+        o.inject(1000003, [100])
+        y_hit = c.spmv(x)
+        assert bits_equal(y_hit, y) and bits_equal(y_hit, o.spmv(x))
+        ev_o, fatal_o = o.events()
+        assert c.events == ev_o == [(2, 1000003, 100)] and not fatal_o
+        # a low column bit flipped where sec7 sees it: repaired before the product is placed, nothing moves
+        c.ctx.inject_at(c.A, 20000001, [2])
+        o.inject(20000001, [2])
+        assert bits_equal(c.spmv(x), o.spmv(x)) and c.events[1:] == o.events()[0] == [(2, 20000001, 2)]
+        o.close()
     finally:
         c.close()
         k.close()
