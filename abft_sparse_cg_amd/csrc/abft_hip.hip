@@ -373,6 +373,21 @@ static void matrix_free(abft_hip_matrix *m) {
                 100.0 * (t[5] - t[0] - t[1] - t[2] - t[3] - t[4]) / t[5]);
     }
   }
+  if (m->use_panels && m->panels.debug) {
+    unsigned long long t[16] = {0};
+    if (hipMemcpy(t, m->panels.debug, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess)
+      for (int h = 0; h < 2; h++) {
+        const unsigned long long *q = t + 8 * h;
+        if (!q[7]) continue;
+        unsigned long long known = 0;
+        for (int k = 0; k < 7; k++) known += q[k];
+        fprintf(stderr, "panel phases, %s launch (%% of workgroup time): segment tables %.1f, barrier before tile %.1f, stage "
+                "(loads, ECC, gathers, LDS writes) %.1f, barrier after %.1f, ordered adds %.1f, y in %.1f, y out + product %.1f, "
+                "rest %.1f\n", h ? "later" : "first", 100.0 * q[0] / q[7], 100.0 * q[1] / q[7], 100.0 * q[2] / q[7],
+                100.0 * q[3] / q[7], 100.0 * q[4] / q[7], 100.0 * q[5] / q[7], 100.0 * q[6] / q[7],
+                100.0 * (double)(q[7] - known) / q[7]);
+      }
+  }
   for (void *p : m->allocs) (void)hipFree(p);
   delete m;
 }
@@ -852,6 +867,14 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     m->panels.seg_ptr = d_segptr;
     m->panels.ngroups = pb.ngroups;
     m->panels.npanels = pb.npanels;
+    m->panels.debug = nullptr;
+    if (getenv("ABFT_HIP_PANEL_DEBUG")) {  // phase clocks of a -DABFT_DBG_STAMPS build, printed when the matrix is destroyed
+      unsigned long long *d_dbg = nullptr;
+      const unsigned long long z[16] = {0};
+      if ((rc = dev_upload(m, &d_dbg, z, 16, 16))) return rc;
+      HIPCHK(hipStreamSynchronize(m->ctx->stream));
+      m->panels.debug = d_dbg;
+    }
   } else if ((rc = dev_upload(m, &A.cols, columns, (size_t)nnz, padded)) ||
              (rc = dev_upload(m, &A.vals, values, (size_t)nnz, padded))) {
     matrix_free(m);
@@ -952,6 +975,14 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     m->panels.seg_ptr = d_segptr;
     m->panels.ngroups = pb.ngroups;
     m->panels.npanels = pb.npanels;
+    m->panels.debug = nullptr;
+    if (getenv("ABFT_HIP_PANEL_DEBUG")) {  // phase clocks of a -DABFT_DBG_STAMPS build, printed when the matrix is destroyed
+      unsigned long long *d_dbg = nullptr;
+      const unsigned long long z[16] = {0};
+      if ((rc = dev_upload(m, &d_dbg, z, 16, 16))) return rc;
+      HIPCHK(hipStreamSynchronize(m->ctx->stream));
+      m->panels.debug = d_dbg;
+    }
   }
   hipError_t e = launch_encode_coo(mode, A.elems, A.nnz, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -42,6 +42,7 @@ struct CsrPanels {
   const uint32_t *seg_base;  // ngroups * npanels + 1 : first element of each segment
   const uint16_t *seg_ptr;   // per segment ABFT_PANEL_ROWS + 1 row offsets relative to seg_base
   uint32_t ngroups, npanels;
+  unsigned long long *debug;  // optional (ABFT_HIP_PANEL_DEBUG, -DABFT_DBG_STAMPS builds): 2 x 8 phase clocks, first / later launches
 };
 // Sweep layout: the panel layout's successor (same idea: (output group, gather-index panel)
 // segments, outputs' additions in the caller's order) run as ONE persistent launch:

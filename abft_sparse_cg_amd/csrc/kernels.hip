@@ -1057,6 +1057,14 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
   if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
 }
 
+#ifdef ABFT_DBG_STAMPS  // timing build: where a workgroup's time goes (wave 0's clock), summed into the layout's debug words (sweep: L.debug[4..9], COO panels: P.debug[0..7])
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define STAMP_ADD(slot, a, b) dbg_t[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
+
 // Panel-layout COO SpMV: the CSR panel kernel with (output group, row panel)
 // segments of 16-byte elements; outputs are the reference's result[col], the
 // gather index is the element's row (COO/CPUContext.cpp:111-120).
@@ -1070,15 +1078,28 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
   __shared__ __attribute__((aligned(16))) double s_prod[TILE];
   __shared__ __attribute__((aligned(16))) uint32_t s_col[TILE];
   double dsum = 0.0;
+#ifdef ABFT_DBG_STAMPS
+  // [0] segment tables (seg_base, 16-bit offsets)  [1] barrier in front of a tile  [2] staging (loads, ECC, gathers,
+  // LDS writes)  [3] barrier behind it  [4] ordered adds  [5] y prologue  [6] y epilogue + fused product  [7] total
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  STAMP(t_begin);
+#endif
   for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x) {
     const uint32_t out0 = g * ABFT_PANEL_ROWS;
     double acc[RPT];
+    STAMP(t_p0);
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
       acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
     }
+#ifdef ABFT_DBG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(t_p1);
+    STAMP_ADD(5, t_p0, t_p1);
     for (uint32_t c = c0; c < c1; c++) {
+      STAMP(t_s0);
       const uint32_t seg = g * P.npanels + c;
       const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
       if (e0 == e1) continue;  // uniform
@@ -1090,11 +1111,20 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
         gs[j] = e0 + ptr[r];
         ge[j] = e0 + ptr[r + 1];
       }
+#ifdef ABFT_DBG_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      STAMP(t_s1);
+      STAMP_ADD(0, t_s0, t_s1);
       for (uint32_t lo = e0; lo < e1;) {
         const uint32_t hi = min(e1, lo + TILE);
+        STAMP(t_a);
         __syncthreads();
+        STAMP(t_b);
         coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod, s_col);
+        STAMP(t_c);
         __syncthreads();
+        STAMP(t_d);
 #pragma unroll
         for (int j = 0; j < RPT; j++) {
           const uint32_t a0 = max(gs[j], lo), a1 = min(ge[j], hi);
@@ -1105,9 +1135,15 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
             acc[j] = t;
           }
         }
+        STAMP(t_e);
+        STAMP_ADD(1, t_a, t_b);
+        STAMP_ADD(2, t_b, t_c);
+        STAMP_ADD(3, t_c, t_d);
+        STAMP_ADD(4, t_d, t_e);
         lo = hi;
       }
     }
+    STAMP(t_q0);
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
@@ -1116,8 +1152,17 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
         if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
       }
     }
+    STAMP(t_q1);
+    STAMP_ADD(6, t_q0, t_q1);
   }
   if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
+#ifdef ABFT_DBG_STAMPS
+  if (threadIdx.x == 0 && P.debug) {
+    STAMP(t_end);
+    dbg_t[7] = t_end - t_begin;
+    for (int k = 0; k < 8; k++) atomicAdd(P.debug + (c0 > 0 ? 8 : 0) + k, dbg_t[k]);
+  }
+#endif
 }
 
 template <int MODE>
@@ -1247,13 +1292,6 @@ __device__ __forceinline__ uint32_t board_min(const BoardView &v) {
   return min(min(r0, r1), min(r2, r3));
 }
 
-#ifdef ABFT_DBG_STAMPS  // timing build: where a workgroup's time goes (wave 0's clock), summed into L.debug[4..9]
-#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define STAMP_ADD(slot, a, b) dbg_t[slot] += (b) - (a)
-#else
-#define STAMP(var)
-#define STAMP_ADD(slot, a, b)
-#endif
 
 // Sweep-layout SpMV (CSR; see SweepLayout).  Stages a segment tile by tile through LDS with
 // the same branch-free load phase as the streaming kernel (ECC in registers, cold path out

@@ -27,11 +27,11 @@ public:
                                         long long count) = 0;
 
   // The loop of cg.cpp:87-118 for a fixed iteration count (-c 0) with alpha and beta kept on
-  // the device: r = b, p = r, then `warmup` untimed iterations and `blocks` back-to-back blocks
-  // of `steps` timed ones (each block bracketed by a device synchronisation and a barrier
-  // across ranks on both sides; seconds[k] = the slowest rank's time for block k, `blocks`
-  // entries).  *rr = r.r after the last of the warmup + blocks * steps iterations.  ECC events
-  // are reported once, at the end.  false: not supported.
+  // the device, `blocks` times over: r = b, p = r, `warmup` untimed iterations, then `steps` timed
+  // ones (bracketed by a device synchronisation and a barrier across ranks on both sides;
+  // seconds[k] = the slowest rank's time for block k, `blocks` entries).  *rr = r.r after the
+  // warmup + steps iterations of the last block (every block restarts the solve, so the number
+  // of blocks does not change it).  ECC events are reported once, at the end.  false: not supported.
   virtual bool run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w,
                          int warmup, int steps, int blocks, double *seconds, double *rr) = 0;
 };

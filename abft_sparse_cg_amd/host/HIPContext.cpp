@@ -948,22 +948,7 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     fixed_scal_dev_ = (double *)abft_hip_vector_device_ptr(fixed_scal_);
   }
   (void)x;
-  // r = b; p = r; rr = r.r  (cg.cpp:87-91), the scalar staying on the device
-  copy_vector(r, b);
-  copy_vector(p, r);
-  check(abft_hip_dot_dev(ctx_, r->handle, r->handle, fixed_scal_dev_), "abft_hip_dot_dev");
-  if (comm_)
-  {
-    device_allreduce(fixed_scal_dev_);
-    // from here on the two all-reduces of an iteration ride in the tails of the kernels that
-    // finish the shard's sums (the fold of p.w, calc_xr's last block): two launches less per iteration
-    const char *env = getenv("ABFT_COMM_FUSE_ALLREDUCE");
-    if (peers_ok_ && !(env && !strcmp(env, "0")))
-    {
-      check(abft_hip_peer_board_fuse(ctx_, 1), "abft_hip_peer_board_fuse");
-      fuse_allreduce_ = true;
-    }
-  }
+  if (blocks < 1) blocks = 1;
   // Replay: the iteration is captured once per parity (the rr pairs swap roles) and launched as
   // a graph -- kernels, the exchange and both all-reduces are graph nodes.  Not with host-staged
   // collectives (they synchronise).  ABFT_CG_GRAPH=0 keeps the eager enqueue.  The first two
@@ -979,11 +964,8 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     const char *env = getenv("ABFT_CG_EXCHANGE_BESIDE");
     fixed_beside_ = graph && comm_ && peer_xchg_ok_ && has_interior_ && env && !strcmp(env, "1");
   }
-  int done = 0;
-  if (blocks < 1) blocks = 1;
-  const int total = warmup + steps * blocks;
-  // clock reads at the start of every block and after the last one, each behind a device
-  // synchronisation + a barrier across ranks: block k runs between marks k and k + 1
+  // clock reads at the start and at the end of every block's timed steps, each behind a device
+  // synchronisation + a barrier across ranks
   std::vector<double> marks;
   auto mark = [&]()
   {
@@ -991,58 +973,86 @@ bool HIPContextBase::run_fixed(cg_matrix *A, cg_vector *b, cg_vector *x, cg_vect
     if (comm_) comm_->barrier();
     marks.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
   };
-  for (int it = 0; it < total; it++)
+  int done = 0;
+  // Every block is the whole run again -- r = b, p = r, rr = r.r, `warmup` untimed iterations, `steps` timed
+  // ones -- so that rr after the last block is rr after warmup + steps iterations whatever the number of
+  // blocks (comparable across records), and a matrix on which CG converges fast is not iterated on until
+  // rr underflows to 0 and alpha = 0 / 0 (configs[3]'s matrix: rr falls by ~0.44 per iteration).
+  for (int blk = 0; blk < blocks; blk++)
   {
-    if (it >= warmup && (it - warmup) % steps == 0)
-      mark();
-    const int parity = it & 1;
-    if (graph && it >= 2)
+    // r = b; p = r; rr = r.r  (cg.cpp:87-91), the scalar staying on the device
+    copy_vector(r, b);
+    copy_vector(p, r);
+    check(abft_hip_dot_dev(ctx_, r->handle, r->handle, fixed_scal_dev_), "abft_hip_dot_dev");
+    if (comm_ && blk == 0)
     {
-      if (!fixed_graph_[parity])
+      device_allreduce(fixed_scal_dev_);
+      // from here on the two all-reduces of an iteration ride in the tails of the kernels that
+      // finish the shard's sums (the fold of p.w, calc_xr's last block): two launches less per iteration
+      // (and a restarting block's r.r arrives summed over the ranks by its own tail)
+      const char *env = getenv("ABFT_COMM_FUSE_ALLREDUCE");
+      if (peers_ok_ && !(env && !strcmp(env, "0")))
       {
-        int rc = abft_hip_graph_begin(ctx_);
-        if (rc == ABFT_OK)
-        {
-          fixed_iteration(A, x, r, p, w, parity);
-          rc = abft_hip_graph_end(ctx_, &fixed_graph_[parity]);
-        }
-        if (rc != ABFT_OK)
-        {
-          fprintf(stderr, "hip backend: hipGraph capture of the CG iteration failed (%s); running eagerly\n",
-                  abft_hip_last_error());
-          graph = false;
-          fixed_beside_ = false;
-          fixed_graph_[parity] = NULL;
-          fixed_iteration(A, x, r, p, w, parity);
-          done++;
-          continue;
-        }
-      }
-      const bool first_replay = !replayed_[parity];
-      check(abft_hip_graph_launch(fixed_graph_[parity]), "abft_hip_graph_launch");
-      if (first_replay && comm_)
-      {
-        // a fresh capture that holds collectives: wait for its first replay under a deadline, so
-        // that a stack on which they cannot run from a graph ends the job with a message
-        // (ABFT_CG_GRAPH=0 avoids graphs) instead of hanging it
-        replayed_[parity] = true;
-        if (abft_hip_synchronize_timeout(ctx_, 180.0) != ABFT_OK)
-        {
-          fflush(stdout);
-          fprintf(stderr, "hip backend: the first hipGraph replay of the CG iteration did not finish (%s); "
-                  "rerun with ABFT_CG_GRAPH=0\n", abft_hip_last_error());
-          _exit(70);
-        }
+        check(abft_hip_peer_board_fuse(ctx_, 1), "abft_hip_peer_board_fuse");
+        fuse_allreduce_ = true;
       }
     }
-    else
-      fixed_iteration(A, x, r, p, w, parity);
-    done++;
+    else if (comm_)
+      device_allreduce(fixed_scal_dev_);  // (nothing to do when the reduction's tail has summed it)
+    done = 0;
+    for (int it = 0; it < warmup + steps; it++)
+    {
+      if (it == warmup)
+        mark();
+      const int parity = it & 1;
+      if (graph && (it >= 2 || blk > 0))
+      {
+        if (!fixed_graph_[parity])
+        {
+          int rc = abft_hip_graph_begin(ctx_);
+          if (rc == ABFT_OK)
+          {
+            fixed_iteration(A, x, r, p, w, parity);
+            rc = abft_hip_graph_end(ctx_, &fixed_graph_[parity]);
+          }
+          if (rc != ABFT_OK)
+          {
+            fprintf(stderr, "hip backend: hipGraph capture of the CG iteration failed (%s); running eagerly\n",
+                    abft_hip_last_error());
+            graph = false;
+            fixed_beside_ = false;
+            fixed_graph_[parity] = NULL;
+            fixed_iteration(A, x, r, p, w, parity);
+            done++;
+            continue;
+          }
+        }
+        const bool first_replay = !replayed_[parity];
+        check(abft_hip_graph_launch(fixed_graph_[parity]), "abft_hip_graph_launch");
+        if (first_replay && comm_)
+        {
+          // a fresh capture that holds collectives: wait for its first replay under a deadline, so
+          // that a stack on which they cannot run from a graph ends the job with a message
+          // (ABFT_CG_GRAPH=0 avoids graphs) instead of hanging it
+          replayed_[parity] = true;
+          if (abft_hip_synchronize_timeout(ctx_, 180.0) != ABFT_OK)
+          {
+            fflush(stdout);
+            fprintf(stderr, "hip backend: the first hipGraph replay of the CG iteration did not finish (%s); "
+                    "rerun with ABFT_CG_GRAPH=0\n", abft_hip_last_error());
+            _exit(70);
+          }
+        }
+      }
+      else
+        fixed_iteration(A, x, r, p, w, parity);
+      done++;
+    }
+    // the end of the block's timed region: device synchronisation + barrier, then the clock -- before any teardown
+    mark();
   }
-  // the end of the timed region: device synchronisation + barrier, then the clock -- before any teardown
-  mark();
   std::vector<double> dts((size_t)blocks, 0.0);
-  for (int k = 0; k < blocks; k++) dts[k] = marks[k + 1] - marks[k];
+  for (int k = 0; k < blocks; k++) dts[k] = marks[2 * k + 1] - marks[2 * k];
   // The graphs hold the device pointers of A, x, r, p, w, of the exchange's description and side
   // stream, and the fuse / beside decisions of THIS call: they must not outlive it (another matrix,
   // other vectors or a re-attached exchange would replay stale pointers).

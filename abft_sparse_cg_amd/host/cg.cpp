@@ -99,8 +99,8 @@ void usage(const char *argv0)
          "  -q  --quiet                 Do not print the per-iteration residual\n"
          "      --bench  W,K[,B]        Fixed-iteration run with alpha and beta kept on the device\n"
          "                              (the loop of -c 0 without per-iteration host round trips):\n"
-         "                              W untimed iterations, then B (default 1) back-to-back blocks of\n"
-         "                              K timed ones; prints a 'bench:' line with the median block\n");
+         "                              B (default 1) times: r = b, W untimed iterations, K timed ones;\n"
+         "                              prints a 'bench:' line with the median block\n");
   printf("\n");
 }
 
@@ -370,7 +370,8 @@ int main(int argc, char *argv[])
     const double seconds = sorted[sorted.size() / 2];
     printf("bench: ranks %d warmup %d steps %d seconds %.9f iterations_per_second %.3f rr %a\n", ext->ext_size(),
            o.bench_warmup, o.bench_steps, seconds, o.bench_steps / seconds, rr_last);
-    printf("bench_blocks: blocks %d iterations_run %d seconds", o.bench_blocks, o.bench_warmup + o.bench_blocks * o.bench_steps);
+    // (every block restarts the solve: rr above is the residual after warmup + steps iterations)
+    printf("bench_blocks: blocks %d iterations_per_block %d seconds", o.bench_blocks, o.bench_warmup + o.bench_steps);
     for (double t : block_seconds) printf(" %.9f", t);
     printf("\n");
     context->destroy_matrix(A);

@@ -166,19 +166,29 @@ def single(args):
         ctx.calc_p(p, r, fdiv(rr_new, state["rr"]))
         state["rr"] = rr_new
 
-    for _ in range(args.warmup):
-        step()
+    def restart():
+        # r = b; p = r; rr = r.r (cg.cpp:87-91), then the warm-up steps
+        ctx.copy_vector(r, b)
+        ctx.copy_vector(p, r)
+        state["rr"] = ctx.dot(r, r)
+        for _ in range(args.warmup):
+            step()
+
+    restart()
     if not args.no_profile:
         # HIP-event brackets inside the timed region on sampled SpMV launches (a bracket
         # serialises the launches around it: sampling all of them costs ~3 %): every 4th,
         # or more often when the run is short, so that at least ~25 launches are averaged
         stride = 1 if args.profile_all else max(1, min(4, args.steps // 25))
         ctx.profile(0xF if args.profile_all else 1 << capi.K_SPMV, stride=stride)
-    # The timed region: exactly `steps` iterations between two synchronisations -- timed BLOCKS times back
-    # to back (a 5 ms window is shorter than this pool's run-to-run spread): `value` comes from the median
-    # block, the fastest and the slowest ride along as value_max / value_min.
+    # The timed region: exactly `steps` iterations between two synchronisations -- BLOCKS times (a 5 ms window
+    # is shorter than this pool's run-to-run spread), every block the whole run again (r = b, warm-up, timed
+    # steps: rr at the end is rr after warmup + steps iterations, whatever BLOCKS is): `value` comes from the
+    # median block, the fastest and the slowest ride along as value_max / value_min.
     block_dt = []
-    for _ in range(BLOCKS):
+    for blk in range(BLOCKS):
+        if blk:
+            restart()
         ctx.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -321,9 +331,9 @@ def parse_cpp(p):
     if m:
         out.update(ranks=int(m.group(1)), seconds=float(m.group(4)), rr=float.fromhex(m.group(6)))
         # the K timed steps ran as B back-to-back blocks; `seconds` above is the median block
-        bl = re.search(r"^bench_blocks: blocks (\d+) iterations_run (\d+) seconds((?: [0-9.]+)+)$", p.stdout, re.M)
+        bl = re.search(r"^bench_blocks: blocks (\d+) iterations_per_block (\d+) seconds((?: [0-9.]+)+)$", p.stdout, re.M)
         if bl:
-            out.update(block_seconds=[float(t) for t in bl.group(3).split()], iterations_run=int(bl.group(2)))
+            out.update(block_seconds=[float(t) for t in bl.group(3).split()], iterations_per_block=int(bl.group(2)))
         h = re.search(r"^matrix size +=\s+(\d+) x", p.stdout, re.M)
         z = re.search(r"^number of non-zeros +=\s+(\d+) ", p.stdout, re.M)
         out.update(N=int(h.group(1)), nnz=int(z.group(1)))
@@ -409,8 +419,9 @@ def block_stats(job, steps):
     bs = job.get("block_seconds") or [job["seconds"]]
     return {"it_per_s": round(steps / job["seconds"], 2), "ms_per_step": round(job["seconds"] / steps * 1e3, 4),
             "blocks": len(bs), "it_per_s_min": round(steps / max(bs), 2), "it_per_s_max": round(steps / min(bs), 2),
-            "value_is": "median of %d back-to-back blocks of %d timed steps" % (len(bs), steps),
-            "iterations_run": job.get("iterations_run"), "rr_after_last_step": job["rr"]}
+            "value_is": "median of %d blocks of %d timed steps (every block: r = b, the warm-up steps, the timed steps)"
+                        % (len(bs), steps),
+            "iterations_per_block": job.get("iterations_per_block"), "rr_after_last_step": job["rr"]}
 
 
 EXTRA_SPEC_MULTI = os.environ.get("ABFT_BENCH_EXTRA_SPEC", "random:4194304,24,1")  # (override: tests)
@@ -468,13 +479,14 @@ def main():
         out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
                     "blocks": len(block_dt), "value_min": round(args.steps / max(block_dt), 2),
                     "value_max": round(args.steps / min(block_dt), 2),
-                    "value_is": "median of %d back-to-back blocks of %d timed steps" % (len(block_dt), args.steps),
+                    "value_is": "median of %d blocks of %d timed steps (every block: r = b, the warm-up steps, the timed steps)"
+                                % (len(block_dt), args.steps),
                     "config": {"workload": "cg-csr -t hip -m %s, synthetic %s" % (args.mode, args.spec)
                                if args.fmt == "csr" else "cg-coo -t hip -m %s, synthetic %s" % (args.mode, args.spec),
                                "N": n, "nnz": nnz, "format": args.fmt, "mode": args.mode, "parallelism": "1 GPU",
                                "rr_after_last_step": rr,
-                               # rr is the residual after ALL of these (warm-up + every block), not after K steps
-                               "iterations_run": args.warmup + len(block_dt) * args.steps},
+                               # every block restarts the solve: rr is the residual after warmup + steps iterations
+                               "iterations_per_block": args.warmup + args.steps},
                     "roofline": roof, "cpu_baseline": cpu, "kernels": kernels})
         if probe:
             out["stream_probe"] = probe
@@ -512,7 +524,8 @@ def main():
                                                   args.gpus, "replayed as a hipGraph" if hl["graph_replay"] else
                                                   ("enqueued eagerly, every collective on the collective layer (the default form failed: first_attempt)"
                                                    if "first_attempt" in hl else "enqueued eagerly (ABFT_CG_GRAPH=0)")),
-                               "rr_after_last_step": hl["rr_after_last_step"], "iterations_run": hl["iterations_run"]},
+                               "rr_after_last_step": hl["rr_after_last_step"],
+                               "iterations_per_block": hl["iterations_per_block"]},
                     "roofline": roof, "cpu_baseline": None,
                     # the record of an unattended run: what carried it, and that its ranks solved the same system
                     "transport_by_rank": hl["transport_by_rank"], "rr_check": hl.get("rr_check")})

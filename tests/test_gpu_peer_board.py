@@ -406,3 +406,115 @@ def test_one_way_windows_wait_for_the_reader_before_reusing_an_outbox(two_ranks_
         assert np.array_equal(got, want), k
         assert np.array_equal(ctxs[0].download(full[0]), src)
     assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
+
+
+EIGHT_RANKS = r'''
+import ctypes as C, sys
+import numpy as np
+import abft_sparse_cg_amd as amd
+from abft_sparse_cg_amd import capi
+L = capi.load()
+G = 8
+ctxs = [amd.HIPContext("none", "csr") for _ in range(G)]
+pairs = [c.create_vector(2) for c in ctxs]
+boards = (C.c_void_p * G)()
+for r, c in enumerate(ctxs):
+    p = C.c_void_p()
+    capi.check(L.abft_hip_peer_board_device_alloc(c.h, C.byref(p)))
+    boards[r] = p.value
+for r, c in enumerate(ctxs):
+    capi.check(L.abft_hip_peer_board_attach_device(c.h, boards, r, G, 30.0))
+def read(c, v):
+    a, e = C.c_double(), C.c_double()
+    capi.check(L.abft_hip_read_pair(c.h, v.device_ptr, C.byref(a), C.byref(e)))
+    return a.value, e.value
+rng = np.random.default_rng(8)
+for k in range(6):  # both rows of the board, three times
+    mine = [np.array([rng.standard_normal() * 10.0 ** rng.integers(-8, 8), float(rng.integers(0, 3))]) for _ in ctxs]
+    for c, p, m in zip(ctxs, pairs, mine):
+        c.upload(p, m)
+    for c, p in zip(reversed(ctxs), reversed(pairs)):  # the last rank first: arrival order must not matter
+        capi.check(L.abft_hip_allreduce_pair_peers(c.h, p.device_ptr))
+    got = [read(c, p) for c, p in zip(ctxs, pairs)]
+    s, e = 0.0, 0.0
+    for m in mine:  # rank order
+        s += m[0]; e += m[1]
+    assert all(g == (s, e) for g in got), (k, got, (s, e))
+# in the tails of the reductions, every rank a different length
+vecs = []
+for r, c in enumerate(ctxs):
+    m = 1000 + 9001 * r
+    a, b = c.create_vector(m), c.create_vector(m)
+    c.upload(a, rng.standard_normal(m)); c.upload(b, rng.standard_normal(m))
+    vecs.append((a, b))
+def both(fused):
+    for c in ctxs:
+        capi.check(L.abft_hip_peer_board_fuse(c.h, 1 if fused else 0))
+    for c, p, (a, b) in zip(ctxs, pairs, vecs):
+        capi.check(L.abft_hip_dot_dev(c.h, a.h, b.h, p.device_ptr))
+        if not fused:
+            capi.check(L.abft_hip_allreduce_pair_peers(c.h, p.device_ptr))
+    return [read(c, p) for c, p in zip(ctxs, pairs)]
+plain, fused = both(False), both(True)
+assert len(set(plain)) == 1 and fused == plain, (plain, fused)
+assert not any(L.abft_hip_peer_board_failed(c.h) for c in ctxs)
+# the window exchange with 8 ranks: a ring of halos, every rank reads 5 entries of each neighbour's slot
+box = 4096
+regions = (C.c_void_p * G)()
+for r, c in enumerate(ctxs):
+    p = C.c_void_p()
+    capi.check(L.abft_hip_peer_exchange_device_alloc(c.h, G, box, C.byref(p)))
+    regions[r] = p.value
+class Piece(C.Structure):
+    _fields_ = [("peer", C.c_int), ("vector_offset", C.c_uint32), ("count", C.c_uint32), ("box_offset", C.c_uint64)]
+def pieces(items):
+    arr = (Piece * max(1, len(items)))()
+    for a, (peer, voff, count, boff) in zip(arr, items):
+        a.peer, a.vector_offset, a.count, a.box_offset = peer, voff, count, boff
+    return arr
+slot = 100
+for r, c in enumerate(ctxs):
+    lo, hi = (r - 1) % G, (r + 1) % G
+    # my outbox: the head of my slot for the rank below (box offset 0), the tail for the rank above (offset 256);
+    # a rank lists its pairs in ascending peer order
+    out = sorted([(lo, r * slot, 5, 0), (hi, r * slot + slot - 5, 5, 256)])
+    # I read the tail of the slot below (it sits at offset 256 of ITS outbox) and the head of the slot above (offset 0)
+    inn = sorted([(lo, lo * slot + slot - 5, 5, 256), (hi, hi * slot, 5, 0)])
+    capi.check(L.abft_hip_peer_exchange_attach_device(c.h, regions, r, G, box, pieces(out), 2, pieces(inn), 2, 30.0))
+full = [c.create_vector(G * slot) for c in ctxs]
+for k in range(4):
+    mine = [rng.standard_normal(slot) for _ in ctxs]
+    for r, (c, v) in enumerate(zip(ctxs, full)):
+        h = np.full(G * slot, -1.0 - k)
+        h[r * slot:(r + 1) * slot] = mine[r]
+        c.upload(v, h)
+    for c, v in zip(reversed(ctxs), reversed(full)):
+        capi.check(L.abft_hip_peer_exchange(c.h, v.h))
+    for r, (c, v) in enumerate(zip(ctxs, full)):
+        got = c.download(v)
+        lo, hi = (r - 1) % G, (r + 1) % G
+        want = np.full(G * slot, -1.0 - k)
+        want[r * slot:(r + 1) * slot] = mine[r]
+        want[lo * slot + slot - 5:lo * slot + slot] = mine[lo][-5:]
+        want[hi * slot:hi * slot + 5] = mine[hi][:5]
+        assert np.array_equal(got, want), (k, r)
+assert not any(L.abft_hip_peer_exchange_failed(c.h) for c in ctxs)
+for c in ctxs:
+    c.close()
+print("eight ranks ok")
+'''
+
+
+def test_board_and_windows_with_eight_ranks():
+    """G = 8 (SURVEY 8f row 1): the device-memory board (plain all-reduce, both rows; in the tails of the
+    reductions) and the pushed window exchange (a ring of halos) with EIGHT contexts of one process standing in
+    for eight ranks.  (Eight processes cannot share the one GPU of this pool's boxes: at most six may use a card
+    at once; five do beside the test process, at configs[3]'s full size, in test_gpu_cli.py.)  In a child process: eight contexts whose
+    kernels wait for each other need eight hardware queues (GPU_MAX_HW_QUEUES; the runtime's default is four
+    per process, read when it initialises)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16", PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-c", EIGHT_RANKS], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert p.returncode == 0 and "eight ranks ok" in p.stdout, p.stdout[-800:] + p.stderr[-3000:]
