@@ -52,6 +52,9 @@ struct abft_hip_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   double *partials = nullptr;  // ABFT_MAX_PARTIALS doubles
   uint32_t *ticket = nullptr;  // reduction arrival counter (device)
+  uint32_t *tail_sync = nullptr;  // cg_tail_kernel's hand-off words (device, zero between launches)
+  bool tail_enabled = true;       // ABFT_HIP_TAIL=0: the iteration's tail as its three kernels
+  int tail_cap[2] = {-1, -1};     // workgroups of cg_tail_kernel<1> / <2> that are resident at once (asked once)
   uint32_t seq = 0;            // last sequence number handed to a reduction
   bool spin_wait = true;       // wait for scalars by polling the pinned slot
   HostSlot *host_slot = nullptr;      // pinned, device-visible
@@ -252,6 +255,9 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   HIPCHK(hipMalloc((void **)&ctx->partials, ABFT_MAX_PARTIALS * sizeof(double)));
   HIPCHK(hipMalloc((void **)&ctx->ticket, ABFT_TICKET_WORDS * sizeof(uint32_t)));
   HIPCHK(hipMemset(ctx->ticket, 0, ABFT_TICKET_WORDS * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void **)&ctx->tail_sync, 8 * sizeof(uint32_t)));
+  HIPCHK(hipMemset(ctx->tail_sync, 0, 8 * sizeof(uint32_t)));
+  if (const char *e = getenv("ABFT_HIP_TAIL")) ctx->tail_enabled = strcmp(e, "0") != 0;
   if (const char *e = getenv("ABFT_HIP_SYNC")) ctx->spin_wait = strcmp(e, "stream") != 0;
   if (const char *e = getenv("ABFT_HIP_FUSE_DOT")) ctx->fuse_enabled = strcmp(e, "0") != 0;
   if (const char *e = getenv("ABFT_HIP_FUSE_X")) ctx->defer_enabled = strcmp(e, "0") != 0;
@@ -297,6 +303,7 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipFree(ctx->partials);
   (void)hipFree(ctx->alpha_dev);
   (void)hipFree(ctx->ticket);
+  (void)hipFree(ctx->tail_sync);
   (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
   (void)hipFree(ctx->ring.count);
@@ -1989,9 +1996,17 @@ extern "C" int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, 
 
 // Shared by abft_hip_spmv (dev_pair == nullptr: the fused product, if any, goes to
 // the pinned slot for a following dot) and abft_hip_spmv_dot_dev.
+// `hold` (abft_hip_cg_iteration_dev): the fold of the fused product is not launched; what it needs is left there
+struct HeldFold {
+  bool held = false;
+  FuseOut fuse{};
+  uint32_t nparts = 0;
+  FixArgs fix{};
+};
+
 static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                        abft_hip_vector *result, int vec_offset, double *dev_pair, int part = ABFT_PART_ALL,
-                       int c0 = 0, int c1 = -1) {
+                       int c0 = 0, int c1 = -1, HeldFold *hold = nullptr) {
   if (int rc = bind(ctx)) return rc;
   if (!mat || !vec || !result) return set_err(ABFT_ERR_INVALID, "spmv: null argument");
   if (part < ABFT_PART_ALL || part > ABFT_PART_BOUNDARY) return set_err(ABFT_ERR_INVALID, "spmv: unknown part %d", part);
@@ -2073,6 +2088,13 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
     }
   }
   if (part == ABFT_PART_INTERIOR || !last_range) return ABFT_OK;  // the call that completes the product folds and publishes
+  if (do_fuse && hold) {
+    hold->held = true;
+    hold->fuse = fuse;
+    hold->nparts = nparts;
+    hold->fix = fix;
+    return ABFT_OK;
+  }
   if (do_fuse) {
     KernelTimer t(ctx, ABFT_K_DOT);  // what is left of the dot: one block folding the partials
     ReduceOut big{};  // same outputs as the one-block fold, reached through the reduction protocol
@@ -2125,6 +2147,72 @@ extern "C" int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *ma
                                           abft_hip_vector *result, int vec_offset, double *dev_result, int part) {
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
   return spmv_common(ctx, mat, vec, result, vec_offset, dev_result, part);
+}
+
+// ---- one CG iteration behind its exchange (cg.cpp:97-112), scalars on the device ----------------
+// spmv(A, vec, w) [a part of it] + p.w, then r -= alpha w, r.r, x += alpha p, p = r + beta p with
+// alpha = rr / p.w and beta = rr_new / rr formed on the device.  The same results, bit for bit, as
+// abft_hip_spmv_dot_part_dev + abft_hip_calc_xr_ratio_dev + abft_hip_calc_p_ratio_dev -- but what follows
+// the SpMV (the fold of its fused product, calc_r, calc_px, and with abft_hip_peer_board_fuse the two
+// board all-reduces) runs as ONE launch, cg_tail_kernel, where that applies: x private to the library
+// and not aliased (the conditions of the deferred x update), workgroups all resident.  Otherwise, and
+// with ABFT_HIP_TAIL=0, the three kernels.
+extern "C" int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
+                                         int vec_offset, int part, abft_hip_vector *x, abft_hip_vector *r,
+                                         abft_hip_vector *p, abft_hip_vector *w, const double *dev_rr, double *dev_pw,
+                                         double *dev_rr_new) {
+  if (!dev_rr || !dev_pw || !dev_rr_new) return set_err(ABFT_ERR_INVALID, "null device scalar");
+  if (part == ABFT_PART_INTERIOR) return set_err(ABFT_ERR_INVALID, "cg_iteration: the interior part goes through abft_hip_spmv_dot_part_dev");
+  HeldFold hold;
+  if (int rc = spmv_common(ctx, mat, vec, w, vec_offset, dev_pw, part, 0, -1, &hold)) return rc;
+  if (int rc = check_same(x, r, "cg_iteration")) return rc;
+  if (int rc = check_same(x, p, "cg_iteration")) return rc;
+  if (int rc = check_same(x, w, "cg_iteration")) return rc;
+  const ReduceOut o = reduce_out(ctx, dev_rr_new, false);
+  const int n = x->n;
+  const bool vec2 = (((uintptr_t)x->d | (uintptr_t)r->d | (uintptr_t)p->d | (uintptr_t)w->d) & 15u) == 0;  // (as the three kernels decide)
+  bool merged = hold.held && ctx->tail_enabled && ctx->defer_enabled && n > 0 && !(x->root ? x->root : x)->exposed &&
+                disjoint(x, r) && disjoint(x, p) && disjoint(x, w) && disjoint(r, p) && disjoint(r, w) && disjoint(p, w);
+  uint32_t grid = 0;
+  const uint32_t nbv = (uint32_t)reduce_blocks(n);
+  if (merged) {
+    int &cap = ctx->tail_cap[vec2 ? 1 : 0];
+    if (cap < 0) cap = cg_tail_blocks_per_cu(vec2) * ctx->num_cus;
+    grid = std::min<uint32_t>((nbv + 3u) / 4u, (uint32_t)std::max(cap, 0));
+    merged = grid > 0;
+  }
+  if (!merged) {
+    if (hold.held) {
+      KernelTimer t(ctx, ABFT_K_DOT);
+      ReduceOut big{};
+      big.partials = ctx->partials; big.ticket = ctx->ticket; big.dev_out = hold.fuse.dev_out; big.host = hold.fuse.host;
+      big.ev_count = hold.fuse.ev_count; big.seq = hold.fuse.seq; big.peers = hold.fuse.peers;
+      HIPCHK(launch_fuse_finalize(hold.fuse, hold.nparts, big, hold.fix.on ? &hold.fix : nullptr, ctx->stream));
+    }
+    if (int rc = calc_xr_launch(ctx, x, r, p, w, 0.0, o, dev_rr, dev_pw)) return rc;
+    return calc_p_launch(ctx, p, r, 0.0, dev_rr_new, dev_rr);
+  }
+  ctx->fused.valid = false;
+  TailArgs a{};
+  a.f = hold.fuse;
+  a.nparts = hold.nparts;
+  if (hold.nparts > 8192u) {  // launch_fuse_finalize's rule for many partials
+    uint32_t nb = (hold.nparts + 2047u) / 2048u;
+    if (nb > 64u) nb = 64u;
+    a.fold_nb = nb;
+    a.fold_chunk = (hold.nparts + nb - 1u) / nb;
+  }
+  a.fx = hold.fix;
+  a.o = o;
+  a.rr = dev_rr;
+  a.x = x->d; a.r = r->d; a.p = p->d; a.w = w->d;
+  a.n = n;
+  a.nbv = nbv;
+  a.sync = ctx->tail_sync;
+  a.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
+  KernelTimer t(ctx, ABFT_K_CALC_XR);
+  HIPCHK(launch_cg_tail(a, vec2, grid, ctx->stream));
+  return ABFT_OK;
 }
 
 // ------------------------------------------------------------- graph replay --

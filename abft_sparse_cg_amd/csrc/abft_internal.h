@@ -313,6 +313,24 @@ struct FixArgs {
 FixArgs make_fix_args(int mode, const CooDev &A, const CsrPanels *P, const double *x, double *y, const FuseOut *fuse);
 hipError_t launch_coo_fixup(const FixArgs &fx, hipStream_t s);
 
+// cg_tail_kernel (kernels.hip): fold of the SpMV's fused partials + calc_r + calc_px in one launch
+struct TailArgs {
+  FuseOut f;            // the SpMV's partials, dev_out = the {p.w, events} pair, peers for its all-reduce
+  uint32_t nparts;      // how many partials
+  uint32_t fold_nb, fold_chunk;  // many partials (> 8192): folded in fold_nb chunks first (launch_fuse_finalize's rule); else 0
+  FixArgs fx;           // COO fix-up (on = 0: none)
+  ReduceOut o;          // partials = the context's block partials, dev_out = the {r.r, events} pair, peers
+  const double *rr;     // this iteration's r.r (device)
+  double *x, *r, *p;
+  const double *w;
+  int n;
+  uint32_t nbv;         // reduce_blocks(n): the grid calc_r_kernel / calc_px_kernel would run on
+  uint32_t *sync;       // 5 words, zero between launches: flag A, arrivals B, flag B, exits, arrivals of the chunk fold
+  unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz) a workgroup waits at a hand-off at most
+};
+int cg_tail_blocks_per_cu(bool vec2);
+hipError_t launch_cg_tail(const TailArgs &a, bool vec2, uint32_t grid, hipStream_t s);
+
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);
 // alpha = num ? *num / *den : alpha (device-resident scalars: no host round trip)

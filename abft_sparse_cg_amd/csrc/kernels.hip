@@ -264,14 +264,18 @@ __device__ __forceinline__ unsigned long long peer_check_word(unsigned long long
          ((unsigned long long)__double_as_longlong(v1) << 1 | (unsigned long long)__double_as_longlong(v1) >> 63);
 }
 
-__device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, const PeerArgs &P) {
+// `seq_given` != 0: the caller names the sequence number and says whether this call leaves it in the counter
+// (cg_tail_kernel: two all-reduces in one launch, run by different workgroups -- a counter bumped by the first
+// would sit dirty in that workgroup's L2 when the second reads it)
+__device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, const PeerArgs &P,
+                                                     unsigned long long seq_given = 0ull, bool write_counter = true) {
   __shared__ double s_pv[2][ABFT_PEER_MAX_RANKS];
   __shared__ double s_mine[2];
   __shared__ unsigned long long s_pseq;
   __shared__ uint32_t s_pbad;
   const uint32_t t = threadIdx.x;
   if (t == 0) {
-    const unsigned long long seq = *P.counter + 1ull;  // written by the previous all-reduce on this stream
+    const unsigned long long seq = seq_given ? seq_given : *P.counter + 1ull;  // (counter: written by the previous all-reduce on this stream)
     if (!P.boards) {
       PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
       // two 16-byte stores, {v0, v1} and {sequence number, check word}, not waited for and in no
@@ -340,7 +344,7 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
     }
     v0 = s0;
     v1 = s1;
-    *P.counter = seq;
+    if (write_counter) *P.counter = seq;
   }
 }
 
@@ -2413,6 +2417,235 @@ hipError_t launch_axpy(double *x, const double *p, double alpha, const double *a
     hipLaunchKernelGGL(axpy_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, p, alpha, alpha_ptr, n);
   else
     hipLaunchKernelGGL(axpy_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, x, p, alpha, alpha_ptr, n);
+  return hipGetLastError();
+}
+
+// ---- the tail of a CG iteration in ONE launch (fixed-iteration loop, scalars on the device) ----
+// Behind the SpMV the loop of cg.cpp:100-112 runs three small kernels -- the fold of the fused p.w partials,
+// calc_r (r -= alpha w, r.r), calc_px (x += alpha p, p = r + beta p) -- each ending in a reduction and, across
+// ranks, a board all-reduce.  On a 1/8 shard of configs[3] they move 3 us worth of bytes in 22-26 us: launch
+// boundaries and reduction tails.  cg_tail_kernel is the three in one launch of co-resident workgroups with two
+// grid-wide hand-offs (a flag the other workgroups poll):
+//   A  workgroup 0 folds the SpMV's partials (after the COO fix-up, if any), all-reduces {p.w, events} over the
+//      board and publishes it; every workgroup then forms alpha = rr / p.w
+//   B  r -= alpha w and the block partials of r.r; the workgroup that arrives last folds them, all-reduces
+//      {r.r, events} and publishes; every workgroup then forms beta = rr_new / rr
+//   C  x += alpha p; p = r + beta p
+// Same bits as the three kernels: 1024-thread workgroups stand for four "virtual" 256-thread blocks each (a
+// quarter = 4 waves with its own LDS slots), the virtual blocks walk the vectors exactly as calc_r_kernel /
+// calc_px_kernel blocks do on a grid of reduce_blocks(n), every fold keeps its shape (fuse_finalize_kernel's
+// 1024-thread fold, or fold_partials_kernel's chunks for many partials; reduce_finish's fold of the block
+// partials), and alpha and beta are the same IEEE quotients.  Every wait is bounded (a launch whose workgroups
+// are all resident never waits long; should one ever give up, the scalars become NaN -- loud, not wrong).
+__device__ __forceinline__ double quarter_sum(double v, double *s_w) {  // block_sum for each quarter of 1024 threads
+  v = wave_sum(v);
+  if ((threadIdx.x & 63u) == 63u) s_w[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const uint32_t q4 = (threadIdx.x >> 8) * 4u;
+  return (s_w[q4] + s_w[q4 + 1u]) + (s_w[q4 + 2u] + s_w[q4 + 3u]);
+}
+
+__device__ __forceinline__ bool tail_wait_ge(const uint32_t *word, uint32_t want, unsigned long long ticks) {
+  const unsigned long long t0 = (unsigned long long)wall_clock64();
+  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    if ((unsigned long long)wall_clock64() - t0 > ticks) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
+  __shared__ double s_w[16];
+  __shared__ double s_scal;
+  __shared__ uint32_t s_last;
+  const uint32_t t = threadIdx.x, q = t >> 8, tq = t & 255u;
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  // the board's sequence number as the previous launch left it: this launch's all-reduces are seq0 + 1 and + 2
+  const unsigned long long seq0 = a.f.peers.size ? *a.f.peers.counter : 0ull;
+
+  // ---- A: p.w ----
+  if (a.fx.on && blockIdx.x == 0) {
+    // COO: moved products first (the fix-up corrects partial 0 and rewrites the receiving outputs of w, which the
+    // OTHER workgroups read in phase B: written back to memory before flag A goes up -- the L2s of the XCDs are
+    // not coherent with each other inside a launch; nobody has touched those lines of w in this launch yet)
+    coo_fixup_body(a.fx);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  }
+  if (a.fold_nb) {
+    // many partials: chunks by the first fold_nb virtual blocks, as fold_partials_kernel's workgroups
+    for (uint32_t base = blockIdx.x * 4u; base < a.fold_nb; base += gridDim.x * 4u) {
+      const uint32_t vb = base + q;
+      double acc = 0.0;
+      if (vb < a.fold_nb) {
+        const uint32_t lo = vb * a.fold_chunk, hi = min(a.nparts, lo + a.fold_chunk);
+        for (uint32_t i = lo + tq; i < hi; i += 4u * ABFT_BLOCK) {
+          double v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t j = i + (uint32_t)k * ABFT_BLOCK;
+            v[k] = j < hi ? a.f.partials[j] : 0.0;
+          }
+          acc += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+      }
+      acc = quarter_sum(acc, s_w);
+      if (vb < a.fold_nb && tq == 0) __hip_atomic_store(a.o.partials + vb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
+    if (blockIdx.x * 4u < a.fold_nb && t == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(a.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (blockIdx.x == 0) {
+    double tot = 0.0, evs = 0.0;
+    if (a.fold_nb) {
+      if (t == 0) {
+        const uint32_t senders = min(gridDim.x, (a.fold_nb + 3u) / 4u);
+        s_last = tail_wait_ge(a.sync + 4, senders, a.timeout_ticks) ? 1u : 0u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      double acc = 0.0;
+      for (uint32_t i = tq; i < a.fold_nb; i += ABFT_BLOCK)  // reduce_finish's fold of the chunk sums
+        acc += __hip_atomic_load(a.o.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot = quarter_sum(acc, s_w);
+      if (t == 0 && !s_last) tot = nan;
+    } else {
+      // fuse_finalize_kernel's fold: fixed order, sixteen independent loads in flight per thread
+      double acc = 0.0;
+      for (uint32_t i = t; i < a.nparts; i += 16u * 1024u) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const uint32_t j = i + (uint32_t)k * 1024u;
+          v[k] = j < a.nparts ? a.f.partials[j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k += 4) acc += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
+      }
+      acc = wave_sum(acc);
+      if ((t & 63u) == 63u) s_w[t >> 6] = acc;
+      __syncthreads();
+      if (t == 0)
+        for (int k = 0; k < 16; k++) tot += s_w[k];
+    }
+    if (t == 0) evs = (double)__hip_atomic_load(a.f.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (a.f.peers.size) peer_allreduce_block(tot, evs, a.f.peers, seq0 + 1ull, false);
+    if (t == 0) {
+      __hip_atomic_store(a.f.dev_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.f.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (t == 0) {
+    const bool ok = tail_wait_ge(a.sync + 0, 1u, a.timeout_ticks);
+    const double pw = __hip_atomic_load(a.f.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_scal = ok ? pw : nan;
+  }
+  __syncthreads();
+  const double rr = *a.rr;
+  const double alpha = rr / s_scal;  // cg.cpp:102
+
+  // ---- B: r -= alpha w; r.r  (calc_r_kernel on a grid of nbv blocks) ----
+  const long stride = (long)a.nbv * ABFT_BLOCK * VEC;
+  for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
+    const uint32_t vb = base + q;
+    double acc = 0.0;
+    if (vb < a.nbv) {
+      for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
+        if (VEC == 2 && i + 1 < a.n) {
+          double2 rv = *reinterpret_cast<double2 *>(a.r + i);
+          const double2 wv = *reinterpret_cast<const double2 *>(a.w + i);
+          rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
+          *reinterpret_cast<double2 *>(a.r + i) = rv;
+          acc += rv.x * rv.x;
+          acc += rv.y * rv.y;
+        } else {
+          const double rs = a.r[i] - alpha * a.w[i];
+          a.r[i] = rs;
+          acc += rs * rs;
+        }
+      }
+    }
+    acc = quarter_sum(acc, s_w);
+    if (vb < a.nbv && tq == 0) __hip_atomic_store(a.o.partials + vb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+  }
+  if (t == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t last = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) {  // (uniform in the workgroup)
+    double acc = 0.0;
+    for (uint32_t i = tq; i < a.nbv; i += ABFT_BLOCK)  // fixed order, as reduce_finish
+      acc += __hip_atomic_load(a.o.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    acc = quarter_sum(acc, s_w);
+    double evs = 0.0;
+    if (t == 0) evs = (double)__hip_atomic_load(a.o.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.o.peers.size) peer_allreduce_block(acc, evs, a.o.peers, seq0 + 2ull, true);
+    if (t == 0) {
+      __hip_atomic_store(a.o.dev_out, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.o.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    const bool ok = tail_wait_ge(a.sync + 2, 1u, a.timeout_ticks);
+    const double rn = __hip_atomic_load(a.o.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_scal = ok ? rn : nan;
+  }
+  __syncthreads();
+  const double beta = s_scal / rr;  // cg.cpp:109
+
+  // ---- C: x += alpha p; p = r + beta p  (calc_px_kernel on the same grid) ----
+  for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
+    const uint32_t vb = base + q;
+    if (vb >= a.nbv) continue;
+    for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
+      if (VEC == 2 && i + 1 < a.n) {
+        double2 pv = *reinterpret_cast<double2 *>(a.p + i);
+        double2 xv = *reinterpret_cast<double2 *>(a.x + i);
+        const double2 rv = *reinterpret_cast<const double2 *>(a.r + i);
+        xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+        pv.x = rv.x + beta * pv.x;
+        pv.y = rv.y + beta * pv.y;
+        *reinterpret_cast<double2 *>(a.x + i) = xv;
+        *reinterpret_cast<double2 *>(a.p + i) = pv;
+      } else {
+        const double pv = a.p[i];
+        a.x[i] = a.x[i] + alpha * pv;
+        a.p[i] = a.r[i] + beta * pv;
+      }
+    }
+  }
+  // the last workgroup out leaves the hand-off words as the next launch expects them
+  if (t == 0 && __hip_atomic_fetch_add(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
+    for (int k = 0; k < 5; k++) __hip_atomic_store(a.sync + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int cg_tail_blocks_per_cu(bool vec2) {
+  int n = 0;
+  const hipError_t e = vec2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2>, 1024, 0)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<1>, 1024, 0);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+hipError_t launch_cg_tail(const TailArgs &a, bool vec2, uint32_t grid, hipStream_t s) {
+  if (vec2) hipLaunchKernelGGL(cg_tail_kernel<2>, dim3(grid), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL(cg_tail_kernel<1>, dim3(grid), dim3(1024), 0, s, a);
   return hipGetLastError();
 }
 

@@ -905,18 +905,37 @@ int HIPContextBase::ext_size() { return comm_ ? comm_->size() : 1; }
 void HIPContextBase::fixed_iteration(cg_matrix *A, cg_vector *x, cg_vector *r, cg_vector *p, cg_vector *w, int parity)
 {
   double *cur = fixed_scal_dev_ + 2 * parity, *nxt = fixed_scal_dev_ + 2 * (1 - parity), *pw = fixed_scal_dev_ + 4;
+  // Everything behind the SpMV in one launch (abft_hip_cg_iteration_dev) when no collective call has to
+  // sit between its parts: one process, or the board all-reduces in the kernels' tails.  ABFT_CG_TAIL=0:
+  // the three calls, as rounds 2-3 ran them (same bits).
+  static const bool tail_env = !(getenv("ABFT_CG_TAIL") && !strcmp(getenv("ABFT_CG_TAIL"), "0"));
+  const bool one_call = tail_env && (!comm_ || fuse_allreduce_);
   if (comm_)
   {
     const int off = comm_->rank() * slot_;
+    const bool split = overlap_ || fixed_beside_;
     exchange_begin(p);
-    if (overlap_ || fixed_beside_)
+    if (split)
       check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw, ABFT_PART_INTERIOR),
             "abft_hip_spmv_dot_part_dev");
     exchange_finish(p);
-    check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw,
-                                     (overlap_ || fixed_beside_) ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
+    if (one_call)
+    {
+      check(abft_hip_cg_iteration_dev(ctx_, A->handle, p->full, off, split ? ABFT_PART_BOUNDARY : ABFT_PART_ALL, x->handle,
+                                      r->handle, p->handle, w->handle, cur, pw, nxt),
+            "abft_hip_cg_iteration_dev");
+      return;
+    }
+    check(abft_hip_spmv_dot_part_dev(ctx_, A->handle, p->full, w->handle, off, pw, split ? ABFT_PART_BOUNDARY : ABFT_PART_ALL),
           "abft_hip_spmv_dot_part_dev");
     device_allreduce(pw);
+  }
+  else if (one_call)
+  {
+    check(abft_hip_cg_iteration_dev(ctx_, A->handle, p->handle, 0, ABFT_PART_ALL, x->handle, r->handle, p->handle, w->handle,
+                                    cur, pw, nxt),
+          "abft_hip_cg_iteration_dev");
+    return;
   }
   else
     check(abft_hip_spmv_dot_dev(ctx_, A->handle, p->handle, w->handle, 0, pw), "abft_hip_spmv_dot_dev");

@@ -356,6 +356,21 @@ int abft_hip_matrix_panels(abft_hip_matrix *mat, int *npanels, int *width);
 int abft_hip_spmv_dot_range_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                                 abft_hip_vector *result, int vec_offset, double *dev_result, int c0, int c1);
 
+/* One CG iteration behind its exchange, scalars on the device (reference loop cg.cpp:97-112):
+ *   w = A vec [part: ABFT_PART_ALL, or ABFT_PART_BOUNDARY after an ABFT_PART_INTERIOR call],
+ *   dev_pw = {vec[vec_offset..] . w, events};  alpha = dev_rr[0] / dev_pw[0];
+ *   r -= alpha w;  dev_rr_new = {r . r, events};  beta = dev_rr_new[0] / dev_rr[0];
+ *   x += alpha p;  p = r + beta p.
+ * Bit for bit what abft_hip_spmv_dot_part_dev + abft_hip_calc_xr_ratio_dev + abft_hip_calc_p_ratio_dev
+ * leave behind (with abft_hip_peer_board_fuse the two scalars arrive summed over the ranks, as there),
+ * but everything behind the SpMV -- the fold of the fused product, the r half, the x / p half and the
+ * two board all-reduces -- is ONE launch of co-resident workgroups where that applies (x private to
+ * the library and no operand aliasing another; ABFT_HIP_TAIL=0 keeps the three kernels).  p is the
+ * caller's view of vec's slot (the vector the SpMV read).  Enqueue-only: capturable. */
+int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec, int vec_offset,
+                              int part, abft_hip_vector *x, abft_hip_vector *r, abft_hip_vector *p,
+                              abft_hip_vector *w, const double *dev_rr, double *dev_pw, double *dev_rr_new);
+
 /* ---- graph replay ------------------------------------------------------ */
 
 /* Capture everything enqueued on the context's stream between begin and end -- the

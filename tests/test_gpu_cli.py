@@ -368,11 +368,16 @@ def test_bench_loop_fused_and_unfused_allreduces_same_bits():
     eager = run_ranks(3, args, ("--one-gpu",), env={"ABFT_CG_GRAPH": "0"})
     inline = run_ranks(3, args, ("--one-gpu",), env={"ABFT_CG_EXCHANGE_BESIDE": "1"})  # the exchange on a graph branch of its own
     one = run("csr", args)
-    for p in (fused, apart, eager, inline, one):
+    # round 4: by default everything behind the SpMV is ONE launch (abft_hip_cg_iteration_dev: fold + r half +
+    # x / p half + both board all-reduces); ABFT_CG_TAIL=0 keeps the three kernels -- same bits, at 3 ranks and at 1
+    three_kernels = run_ranks(3, args, ("--one-gpu",), env={"ABFT_CG_TAIL": "0"})
+    one_three = run("csr", args, env={"ABFT_CG_TAIL": "0"})
+    for p in (fused, apart, eager, inline, one, three_kernels, one_three):
         assert p.returncode == 0, p.stderr[-800:]
     a, b, c, e, d = (bench_line(p.stdout) for p in (fused, apart, eager, inline, one))
     assert a[0] == b[0] == c[0] == e[0] == 3 and a[4] == b[4] == c[4] == e[4]
     assert abs(a[4] - d[4]) <= 1e-10 * d[4]
+    assert bench_line(three_kernels.stdout)[4] == a[4] and bench_line(one_three.stdout)[4] == d[4]
 
 
 def test_run_tests_script_passes_column_partitioned_coo():

@@ -1,0 +1,140 @@
+"""abft_hip_cg_iteration_dev: the CG iteration behind its exchange as SpMV + ONE launch (cg_tail_kernel: the fold
+of the fused p.w partials, r -= alpha w with r.r, x += alpha p and p = r + beta p, alpha and beta formed on the
+device; reference loop cg.cpp:97-112) against the three kernels it replaces -- every vector and both scalars bit
+for bit, iteration after iteration, on every layout, with few and with many SpMV partials (the two fold shapes),
+with a vector length that is no multiple of anything, with the COO fix-up in the fold, inside a replayed graph."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _oracle import laplace5, random_spd
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.asarray(a).view(np.uint64)
+
+
+def run_iterations(amd, capi, fmt, mode, mat, iters, one_call, graph=False, flip=None, monkeypatch=None):
+    cols, rows, vals, n = mat
+    ctx = amd.HIPContext(mode, fmt)
+    L, h = ctx.L, ctx.h
+    A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+    if flip:
+        ctx.inject_at(A, flip[0], flip[1])
+    x, r, p, w = (ctx.create_vector(n) for _ in range(4))
+    rng = np.random.default_rng(12)
+    b = rng.random(n)
+    ctx.upload(x, np.zeros(n))
+    ctx.upload(r, b)
+    ctx.upload(p, b)
+    ctx.upload(w, np.zeros(n))
+    sc = ctx.create_vector(6)
+    ctx.upload(sc, np.array([float(b @ b), 0.0, 0.0, 0.0, 0.0, 0.0]))
+    base = sc.device_ptr
+
+    def it(parity):
+        cur, nxt, pw = base + 16 * parity, base + 16 * (1 - parity), base + 32
+        if one_call:
+            capi.check(L.abft_hip_cg_iteration_dev(h, A.h, p.h, 0, capi.PART_ALL, x.h, r.h, p.h, w.h, cur, pw, nxt))
+        else:
+            capi.check(L.abft_hip_spmv_dot_dev(h, A.h, p.h, w.h, 0, pw))
+            capi.check(L.abft_hip_calc_xr_ratio_dev(h, x.h, r.h, p.h, w.h, cur, pw, nxt))
+            capi.check(L.abft_hip_calc_p_ratio_dev(h, p.h, r.h, nxt, cur))
+
+    trace = []
+    if graph:
+        it(0); it(1)
+        graphs = []
+        for parity in (0, 1):
+            capi.check(L.abft_hip_graph_begin(h))
+            it(parity)
+            g = C.c_void_p()
+            capi.check(L.abft_hip_graph_end(h, C.byref(g)))
+            graphs.append(g)
+        for k in range(2, iters):
+            capi.check(L.abft_hip_graph_launch(graphs[k & 1]))
+        for g in graphs:
+            L.abft_hip_graph_destroy(g)
+    else:
+        for k in range(iters):
+            it(k & 1)
+            if k in (0, iters - 1):
+                trace.append([ctx.download(v) for v in (r, p, w)] + [ctx.download(sc)])
+    out = [ctx.download(v) for v in (x, r, p, w)] + [ctx.download(sc)]
+    ctx.close()
+    return out, trace
+
+
+CASES = [
+    ("csr", "secded", "lap", None),      # streaming layout, a few hundred partials
+    ("csr", "none", "lap_big", None),    # 11 000 row blocks: the fold by chunks (fold_partials_kernel's shape)
+    ("csr", "sec8", "rand", None),       # sweep layout (forced below)
+    ("coo", "sec7", "rand", None),       # COO, panel layout (forced)
+    ("coo", "none", "lap", (777, [3])),  # a silently corrupted column: the fix-up runs inside the fold
+]
+
+
+@pytest.mark.parametrize("fmt,mode,which,flip", CASES)
+def test_one_launch_tail_equals_the_three_kernels(fmt, mode, which, flip, monkeypatch):
+    import abft_sparse_cg_amd as amd
+    from abft_sparse_cg_amd import capi
+    if which == "lap":
+        mat = laplace5(61, 47)          # n = 2867: odd, one virtual block only partly filled
+    elif which == "lap_big":
+        mat = laplace5(1500, 1501)
+    else:
+        mat = random_spd(30011, 9, seed=5)
+        monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep" if fmt == "csr" else "panels")
+    iters = 9
+    three, tr3 = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=False, flip=flip)
+    one, tr1 = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=True, flip=flip)
+    for a, b in zip(three, one):
+        assert np.array_equal(bits(a), bits(b))
+    for ta, tb in zip(tr3, tr1):
+        for a, b in zip(ta, tb):
+            assert np.array_equal(bits(a), bits(b))
+    assert np.all(np.isfinite(one[4][[0, 2, 4]])) and one[4][0] > 0
+    # replayed as a graph: the hand-off words are back at zero after every launch
+    replay, _ = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=True, graph=True, flip=flip)
+    for a, b in zip(three, replay):
+        assert np.array_equal(bits(a), bits(b))
+    # ABFT_HIP_TAIL=0: the same entry point runs the three kernels
+    monkeypatch.setenv("ABFT_HIP_TAIL", "0")
+    off, _ = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=True, flip=flip)
+    for a, b in zip(three, off):
+        assert np.array_equal(bits(a), bits(b))
+
+
+def test_one_launch_tail_falls_back_when_x_is_not_private():
+    """x's raw device pointer handed out, or x aliasing p: not the merged launch (the deferred-x conditions), still
+    the same results; a null scalar and the interior part are refused."""
+    import abft_sparse_cg_amd as amd
+    from abft_sparse_cg_amd import capi
+    cols, rows, vals, n = laplace5(40, 40)
+    ctx = amd.HIPContext("secded", "csr")
+    L, h = ctx.L, ctx.h
+    A = ctx.create_matrix(cols, rows, vals, n, len(vals))
+    x, r, p, w = (ctx.create_vector(n) for _ in range(4))
+    b = np.random.default_rng(3).random(n)
+    for v, val in ((x, np.zeros(n)), (r, b), (p, b), (w, np.zeros(n))):
+        ctx.upload(v, val)
+    sc = ctx.create_vector(6)
+    ctx.upload(sc, np.array([float(b @ b), 0.0, 0.0, 0.0, 0.0, 0.0]))
+    base = sc.device_ptr
+    assert L.abft_hip_cg_iteration_dev(h, A.h, p.h, 0, capi.PART_ALL, x.h, r.h, p.h, w.h, None, base + 32, base + 16) != 0
+    assert L.abft_hip_cg_iteration_dev(h, A.h, p.h, 0, capi.PART_INTERIOR, x.h, r.h, p.h, w.h, base, base + 32, base + 16) != 0
+    _ = x.device_ptr  # exposed: the library may no longer delay or merge x's update
+    capi.check(L.abft_hip_cg_iteration_dev(h, A.h, p.h, 0, capi.PART_ALL, x.h, r.h, p.h, w.h, base, base + 32, base + 16))
+    got = [ctx.download(v) for v in (x, r, p, w)]
+    s = ctx.download(sc)
+    ctx.close()
+    # numpy model of one iteration (reductions to tolerance, the element-wise parts exactly given the scalars)
+    alpha = s[0] / s[4]
+    beta = s[2] / s[0]
+    assert np.array_equal(bits(got[1]), bits(b - alpha * got[3]))
+    assert np.array_equal(bits(got[0]), bits(np.zeros(n) + alpha * b))
+    assert np.array_equal(bits(got[2]), bits(got[1] + beta * b))
+    assert abs(s[4] - float(b @ got[3])) <= 1e-12 * abs(s[4]) and abs(s[2] - float(got[1] @ got[1])) <= 1e-12 * s[2]
