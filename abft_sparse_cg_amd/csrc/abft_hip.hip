@@ -124,6 +124,7 @@ struct abft_hip_matrix {
   CooDev coo{};
   double *fuse_partials = nullptr;  // FuseOut buffer (square matrices)
   bool use_panels = false;          // panel layout chosen at create time
+  bool coo_pc = false;              // COO panel layout run by spmv_coo_pc_kernel (producer / consumer waves)
   CsrPanels panels{};
   uint32_t panel_grid = 0;          // workgroups of the panel kernel
   uint32_t panel_chunk = 0;         // panels per launch (0 = all)
@@ -1028,6 +1029,30 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
     m->panel_chunk = (size_t)n_in_b * sizeof(double) <= ((size_t)24 << 20) ? 4 : 2;
     if (const char *e = getenv("ABFT_HIP_PANEL_CHUNK")) m->panel_chunk = (uint32_t)std::max(0L, atol(e));
     if (m->panel_chunk) m->panel_grid = m->panels.ngroups;  // one row group per workgroup between boundaries
+    // COO (round 4): ALL panels in one launch, the workgroups of an XCD held inside one window of x by a progress
+    // board per XCD instead of by kernel boundaries (ABFT_HIP_PANEL_LAG: panels a workgroup may be ahead of the
+    // slowest of its XCD; 0 = the chunked launches above)
+    // (config 5, sec7, same box, us per SpMV: two launches of 4 panels 201-202, one unpaced launch 201, paced with
+    // lag 1 / 2 / 3: 207 / 195-196 / 202; panels of 1.3 MB instead of 2 MB: 223 unpaced, 198 with lag 2 --
+    // gpurun_out/r4/c5_ab3.txt, c5_ab4.txt.  Default: lag 2 when every group has its own resident workgroup.)
+    if (format == ABFT_FMT_COO && mode != ABFT_MODE_CONSTRAINTS) {
+      const char *e = getenv("ABFT_HIP_COO_PC");
+      m->coo_pc = e && strcmp(e, "0") != 0;
+    }
+    const uint32_t resident = (uint32_t)(format != ABFT_FMT_COO ? 0 : (m->coo_pc ? spmv_coo_pc_blocks_per_cu(mode)
+                                                                                : spmv_coo_panels_blocks_per_cu(mode)) * ctx->num_cus);
+    uint32_t lag = (format == ABFT_FMT_COO && m->panels.ngroups <= resident && !getenv("ABFT_HIP_PANEL_CHUNK")) ? 2u : 0u;
+    if (const char *e = getenv("ABFT_HIP_PANEL_LAG")) lag = (uint32_t)std::max(0L, atol(e));
+    if (format == ABFT_FMT_COO && lag > 0) {
+      uint32_t *d_pace = nullptr;
+      std::vector<uint32_t> init(8 * 256, 0xffffffffu);  // 8 boards of PACE_SLOTS "nobody here"
+      if ((rc = dev_upload(m, &d_pace, init.data(), init.size(), init.size()))) { matrix_free(m); *out = nullptr; return rc; }
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      m->panels.pace = d_pace;
+      m->panels.lag = lag;
+      m->panel_chunk = 0;
+      m->panel_grid = std::min<uint32_t>(m->panels.ngroups, std::max(resident, 1u));
+    }
   }
   if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
     // one partial per SpMV workgroup: row blocks (streaming) or output groups (panels)
@@ -2072,8 +2097,12 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
                                     do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
     } else if (mat->fmt == ABFT_FMT_COO && mat->use_panels) {
       nparts = mat->panel_grid;
-      HIPCHK(launch_spmv_coo_panels(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
-                                    do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
+      if (mat->coo_pc)
+        HIPCHK(launch_spmv_coo_pc(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
+                                  do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
+      else
+        HIPCHK(launch_spmv_coo_panels(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
+                                      do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
     } else if (mat->fmt == ABFT_FMT_CSR)
       HIPCHK(launch_spmv_csr(mat->mode, mat->csr, span, vec->d, result->d, ctx->ring, do_fuse ? &fuse : nullptr,
                              ctx->stream));

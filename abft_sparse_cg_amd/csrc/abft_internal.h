@@ -43,6 +43,8 @@ struct CsrPanels {
   const uint16_t *seg_ptr;   // per segment ABFT_PANEL_ROWS + 1 row offsets relative to seg_base
   uint32_t ngroups, npanels;
   unsigned long long *debug;  // optional (ABFT_HIP_PANEL_DEBUG, -DABFT_DBG_STAMPS builds): 2 x 8 phase clocks, first / later launches
+  uint32_t *pace;             // COO panel kernel run as ONE launch over all panels: a progress board per XCD (as SweepLayout), else NULL
+  uint32_t lag;               // workgroups of an XCD stay within `lag` panels of its slowest; 0: no pacing
 };
 // Sweep layout: the panel layout's successor (same idea: (output group, gather-index panel)
 // segments, outputs' additions in the caller's order) run as ONE persistent launch:
@@ -153,6 +155,9 @@ struct CooDev {
 #endif
 #ifndef ABFT_CFG_COO_PANEL_EPT
 #define ABFT_CFG_COO_PANEL_EPT 4  // 16-byte elements per thread per tile of the COO panel kernel
+#endif
+#ifndef ABFT_CFG_COO_PANEL_PREFETCH
+#define ABFT_CFG_COO_PANEL_PREFETCH 0  // COO panel kernel: the next tile's streaming loads issued behind this tile's gathers
 #endif
 #ifndef ABFT_CFG_COO_SCHED_BARRIER
 #define ABFT_CFG_COO_SCHED_BARRIER 1  // bit m: COO kernels of mode m keep their streaming loads together (kernels.hip)
@@ -328,6 +333,10 @@ struct TailArgs {
   uint32_t *sync;       // 5 words, zero between launches: flag A, arrivals B, flag B, exits, arrivals of the chunk fold
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz) a workgroup waits at a hand-off at most
 };
+int spmv_coo_panels_blocks_per_cu(int mode);
+int spmv_coo_pc_blocks_per_cu(int mode);
+hipError_t launch_spmv_coo_pc(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
+                              const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
 int cg_tail_blocks_per_cu(bool vec2);
 hipError_t launch_cg_tail(const TailArgs &a, bool vec2, uint32_t grid, hipStream_t s);
 

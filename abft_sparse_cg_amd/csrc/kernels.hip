@@ -938,6 +938,73 @@ __device__ __forceinline__ void coo_stage(const CooDev &A, const double *__restr
   coo_consume<MODE, EPT>(A, x, ev, lo, hi, t, s_prod, s_col, false, 0u, 0u, unused);
 }
 
+// the same for a PRODUCER wave of spmv_coo_pc_kernel: `tid` = index among the 256 producer threads, loads already in `t`.
+// The cold path is kept OUT of the hot section: an element that fails its check is staged as "no product" and only
+// flagged; behind the LDS writes, where nothing of the tile is live in registers any more, a wave with a flagged lane
+// re-reads those elements, repairs them (ecc_cold: out of line) and overwrites their two LDS slots -- the consumers
+// see the buffer only after that.  (A call inside the hot section costs the callee's registers on top of everything
+// live across it: 88 VGPRs against 64 here.)
+template <int MODE, int EPT>
+__device__ __forceinline__ void coo_consume_pc(const CooDev &A, const double *__restrict__ x, const EventRing &ev,
+                                               uint32_t lo, uint32_t hi, const CooTileRegs<EPT> &t, double *s_prod,
+                                               uint32_t *s_col, uint32_t tid) {
+  uint32_t row[EPT];
+  double val[EPT];
+  bool ok[EPT];
+  uint32_t sus = 0u;  // bit s: element s failed its check
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const uint32_t j = lo + tid + (uint32_t)s * ABFT_BLOCK;
+    const uint32_t w[4] = {t.e[s].x, t.e[s].y, t.e[s].z, t.e[s].w};
+    bool valid = j < hi;
+    if (MODE >= MODE_SED) {
+      if (valid && ecc_suspect<FMT_COO, MODE>(w) != 0) {
+        sus |= 1u << s;
+        valid = false;
+      }
+    }
+    row[s] = w[1];
+    val[s] = as_double(w[2], w[3]);
+    ok[s] = valid;
+    s_col[tid + (uint32_t)s * ABFT_BLOCK] = MODE >= MODE_SED ? (w[0] & ABFT_COLMASK) : w[0];
+  }
+  double xv[EPT];
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const bool in = ok[s] && row[s] < A.n_in;
+#ifdef ABFT_DBG_NOGATHER  // timing-only build: wrong results
+    xv[s] = (double)row[s];
+#else
+    xv[s] = gather_load(x + (in ? row[s] : 0u));
+#endif
+    xv[s] = in ? xv[s] : 0.0;
+  }
+#pragma unroll
+  for (int s = 0; s < EPT; s++) {
+    const double p = val[s] * xv[s];
+    s_prod[tid + (uint32_t)s * ABFT_BLOCK] = ok[s] ? p : 0.0;
+  }
+  if (MODE >= MODE_SED && __builtin_expect(__builtin_amdgcn_ballot_w64(sus != 0u) != 0ull, 0)) {
+    for (int s = 0; s < EPT; s++) {  // (not unrolled: one call site)
+      if (!((sus >> s) & 1u)) continue;
+      const uint32_t j = lo + tid + (uint32_t)s * ABFT_BLOCK;
+      const uint4 el = A.elems[j];
+      EccWords<FMT_COO> ce;
+      ce.w[0] = el.x; ce.w[1] = el.y; ce.w[2] = el.z; ce.w[3] = el.w; ce.rc = 0;
+      ce = ecc_cold<FMT_COO, MODE>(ce, event_index(A, j), ev);
+      double p = 0.0;
+      if (ce.rc > 0) {
+        A.elems[j] = make_uint4(ce.w[0], ce.w[1], ce.w[2], ce.w[3]);  // COO/CPUContext.cpp:255, 310, 364
+        const bool in = ce.w[1] < A.n_in;
+        const double xr = gather_load(x + (in ? ce.w[1] : 0u));
+        p = as_double(ce.w[2], ce.w[3]) * (in ? xr : 0.0);
+      }
+      s_col[tid + (uint32_t)s * ABFT_BLOCK] = ce.w[0] & ABFT_COLMASK;
+      s_prod[tid + (uint32_t)s * ABFT_BLOCK] = p;
+    }
+  }
+}
+
 // Cold: the product staged at LDS slot k (stored position j) belongs to output `col`,
 // not to the group it is stored in.  Queue it for coo_fixup_kernel; a column outside
 // the result vector is dropped (the reference writes out of bounds there: undefined).
@@ -1002,6 +1069,33 @@ __device__ __forceinline__ void lds_ordered_add(const CooDev &A, const EventRing
   }
 }
 
+// The consumer waves' form (spmv_coo_pc_kernel), two-wide: a stranger is noted in a small per-wave LDS list
+// {stored position, column, product} instead of being queued from here -- the out-of-line queueing call would cost
+// the hot loop its callee's registers (98 VGPRs against 62) -- and the wave queues its list once its group is done.
+struct MovedNote { uint32_t j, col; double prod; };
+constexpr uint32_t PC_NOTES = 32;  // per consumer wave and group; more than that in one group: ABFT_EV_MOVED_OVERFLOW
+__device__ __forceinline__ void lds_ordered_add_pc(const double *s_prod, const uint32_t *s_col, uint32_t a, uint32_t b,
+                                                   uint32_t out, uint32_t j0, double &acc, uint32_t *s_ncount,
+                                                   MovedNote *s_notes) {
+  for (uint32_t k = a; k < b; k += 2u) {
+    const uint32_t last = b - 1u, k1 = min(k + 1u, last);
+    const double a0 = s_prod[k], a1 = s_prod[k1];
+    const uint32_t c0 = s_col[k], c1 = s_col[k1];
+    if (c0 == out) acc += a0;
+    if (k + 1u < b && c1 == out) acc += a1;
+    if (__builtin_expect(((c0 ^ out) | (c1 ^ out)) != 0u, 0)) {
+      if (c0 != out) {
+        const uint32_t n = atomicAdd(s_ncount, 1u);
+        if (n < PC_NOTES) { s_notes[n].j = j0 + k; s_notes[n].col = c0; s_notes[n].prod = a0; }
+      }
+      if (k + 1u < b && c1 != out) {
+        const uint32_t n = atomicAdd(s_ncount, 1u);
+        if (n < PC_NOTES) { s_notes[n].j = j0 + k + 1u; s_notes[n].col = c1; s_notes[n].prod = a1; }
+      }
+    }
+  }
+}
+
 // COO SpMV, all modes: result[col] += value * vec[row] (reference
 // COO/CPUContext.cpp:104-121).  Elements are stored grouped by col in caller
 // order, so an output's contributions are added in exactly the order the
@@ -1061,178 +1155,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_kernel(CooDev A, const do
   if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
 }
 
-#ifdef ABFT_DBG_STAMPS  // timing build: where a workgroup's time goes (wave 0's clock), summed into the layout's debug words (sweep: L.debug[4..9], COO panels: P.debug[0..7])
-#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
-#define STAMP_ADD(slot, a, b) dbg_t[slot] += (b) - (a)
-#else
-#define STAMP(var)
-#define STAMP_ADD(slot, a, b)
-#endif
-
-// Panel-layout COO SpMV: the CSR panel kernel with (output group, row panel)
-// segments of 16-byte elements; outputs are the reference's result[col], the
-// gather index is the element's row (COO/CPUContext.cpp:111-120).
-template <int MODE, int EPT, bool FUSE>
-__global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, CsrPanels P,
-                                                                     const double *__restrict__ x,
-                                                                     double *__restrict__ y, EventRing ev,
-                                                                     FuseOut fuse, uint32_t c0, uint32_t c1) {
-  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
-  constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
-  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
-  __shared__ __attribute__((aligned(16))) uint32_t s_col[TILE];
-  double dsum = 0.0;
-#ifdef ABFT_DBG_STAMPS
-  // [0] segment tables (seg_base, 16-bit offsets)  [1] barrier in front of a tile  [2] staging (loads, ECC, gathers,
-  // LDS writes)  [3] barrier behind it  [4] ordered adds  [5] y prologue  [6] y epilogue + fused product  [7] total
-  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  STAMP(t_begin);
-#endif
-  for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x) {
-    const uint32_t out0 = g * ABFT_PANEL_ROWS;
-    double acc[RPT];
-    STAMP(t_p0);
-#pragma unroll
-    for (int j = 0; j < RPT; j++) {
-      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
-      acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
-    }
-#ifdef ABFT_DBG_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    STAMP(t_p1);
-    STAMP_ADD(5, t_p0, t_p1);
-    for (uint32_t c = c0; c < c1; c++) {
-      STAMP(t_s0);
-      const uint32_t seg = g * P.npanels + c;
-      const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
-      if (e0 == e1) continue;  // uniform
-      const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
-      uint32_t gs[RPT], ge[RPT];
-#pragma unroll
-      for (int j = 0; j < RPT; j++) {
-        const uint32_t r = (uint32_t)j * ABFT_BLOCK + threadIdx.x;
-        gs[j] = e0 + ptr[r];
-        ge[j] = e0 + ptr[r + 1];
-      }
-#ifdef ABFT_DBG_STAMPS
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-      STAMP(t_s1);
-      STAMP_ADD(0, t_s0, t_s1);
-      for (uint32_t lo = e0; lo < e1;) {
-        const uint32_t hi = min(e1, lo + TILE);
-        STAMP(t_a);
-        __syncthreads();
-        STAMP(t_b);
-        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod, s_col);
-        STAMP(t_c);
-        __syncthreads();
-        STAMP(t_d);
-#pragma unroll
-        for (int j = 0; j < RPT; j++) {
-          const uint32_t a0 = max(gs[j], lo), a1 = min(ge[j], hi);
-          if (a0 < a1) {
-            double t = acc[j];
-            lds_ordered_add<ABFT_CFG_COO_PANEL_SHORT_SUMS>(A, ev, s_prod, s_col, a0 - lo, a1 - lo,
-                                                           out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x, lo, t);
-            acc[j] = t;
-          }
-        }
-        STAMP(t_e);
-        STAMP_ADD(1, t_a, t_b);
-        STAMP_ADD(2, t_b, t_c);
-        STAMP_ADD(3, t_c, t_d);
-        STAMP_ADD(4, t_d, t_e);
-        lo = hi;
-      }
-    }
-    STAMP(t_q0);
-#pragma unroll
-    for (int j = 0; j < RPT; j++) {
-      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
-      if (o < A.n_out) {
-        y[o] = acc[j];
-        if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
-      }
-    }
-    STAMP(t_q1);
-    STAMP_ADD(6, t_q0, t_q1);
-  }
-  if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
-#ifdef ABFT_DBG_STAMPS
-  if (threadIdx.x == 0 && P.debug) {
-    STAMP(t_end);
-    dbg_t[7] = t_end - t_begin;
-    for (int k = 0; k < 8; k++) atomicAdd(P.debug + (c0 > 0 ? 8 : 0) + k, dbg_t[k]);
-  }
-#endif
-}
-
-template <int MODE>
-static hipError_t launch_coo_panels_mode(const CooDev &A, const CsrPanels &P, const double *x, double *y,
-                                         EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0,
-                                         uint32_t c1, hipStream_t s) {
-  if (fuse)
-    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
-                       P, x, y, ev, *fuse, c0, c1);
-  else
-    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
-                       P, x, y, ev, FuseOut{}, c0, c1);
-  return hipGetLastError();
-}
-
-hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y,
-                                  EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
-                                  hipStream_t s) {
-  if (P.ngroups == 0) return hipSuccess;
-  if (chunk == 0 || chunk > P.npanels) chunk = P.npanels;
-  for (uint32_t c0 = 0; c0 < P.npanels; c0 += chunk) {
-    const uint32_t c1 = c0 + chunk < P.npanels ? c0 + chunk : P.npanels;
-    const FuseOut *f = c1 == P.npanels ? fuse : nullptr;
-    hipError_t e;
-    switch (mode) {
-      case MODE_NONE: e = launch_coo_panels_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
-      case MODE_CONSTRAINTS: e = launch_coo_panels_mode<MODE_CONSTRAINTS>(A, P, x, y, ev, f, grid, c0, c1, s); break;
-      case MODE_SED: e = launch_coo_panels_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
-      case MODE_SEC7: e = launch_coo_panels_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
-      case MODE_SEC8: e = launch_coo_panels_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;
-      case MODE_SECDED: e = launch_coo_panels_mode<MODE_SECDED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
-      default: return hipErrorInvalidValue;
-    }
-    if (e != hipSuccess) return e;
-  }
-  return hipSuccess;
-}
-
-template <int MODE>
-static hipError_t launch_spmv_coo_mode(const CooDev &A, const double *x, double *y, EventRing ev,
-                                       const FuseOut *fuse, hipStream_t s) {
-  if (fuse) {
-    hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT, true>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
-                       x, y, ev, *fuse);
-  } else
-    hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT, false>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
-                       x, y, ev, FuseOut{});
-  return hipGetLastError();
-}
-
-hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
-                           const FuseOut *fuse, hipStream_t s) {
-  if (A.nblk == 0) return hipSuccess;
-  switch (mode) {
-    case MODE_NONE: return launch_spmv_coo_mode<MODE_NONE>(A, x, y, ev, fuse, s);
-    case MODE_CONSTRAINTS: return launch_spmv_coo_mode<MODE_CONSTRAINTS>(A, x, y, ev, fuse, s);
-    case MODE_SED: return launch_spmv_coo_mode<MODE_SED>(A, x, y, ev, fuse, s);
-    case MODE_SEC7: return launch_spmv_coo_mode<MODE_SEC7>(A, x, y, ev, fuse, s);
-    case MODE_SEC8: return launch_spmv_coo_mode<MODE_SEC8>(A, x, y, ev, fuse, s);
-    case MODE_SECDED: return launch_spmv_coo_mode<MODE_SECDED>(A, x, y, ev, fuse, s);
-    default: return hipErrorInvalidValue;
-  }
-}
-
-// ------------------------------------------------------------ sweep-layout SpMV --
-
+// ---- pacing helpers (used by the COO panel kernel and the sweep / slice kernels) ----
 // pace buffer: per XCD a board of PACE_SLOTS progress words (steps completed by the workgroup
 // that owns that slot; ~0u = nobody there, which is also how every workgroup leaves its slot)
 constexpr uint32_t PACE_SLOTS = 256;
@@ -1296,6 +1219,475 @@ __device__ __forceinline__ uint32_t board_min(const BoardView &v) {
   return min(min(r0, r1), min(r2, r3));
 }
 
+
+#ifdef ABFT_DBG_STAMPS  // timing build: where a workgroup's time goes (wave 0's clock), summed into the layout's debug words (sweep: L.debug[4..9], COO panels: P.debug[0..7])
+#define STAMP(var) unsigned long long var; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory")
+#define STAMP_ADD(slot, a, b) dbg_t[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
+
+// Panel-layout COO SpMV: the CSR panel kernel with (output group, row panel)
+// segments of 16-byte elements; outputs are the reference's result[col], the
+// gather index is the element's row (COO/CPUContext.cpp:111-120).
+template <int MODE, int EPT, bool FUSE>
+__global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, CsrPanels P,
+                                                                     const double *__restrict__ x,
+                                                                     double *__restrict__ y, EventRing ev,
+                                                                     FuseOut fuse, uint32_t c0, uint32_t c1) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[TILE];
+  double dsum = 0.0;
+  // Pacing, as in the sweep kernel (speed only, every wait bounded): with all panels in one launch what keeps the
+  // workgroups of an XCD inside one window of x is a progress board per XCD -- a workgroup starts panel step s
+  // only when the slowest of its XCD has completed step s - lag.
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t nsteps = c1 - c0;
+  const bool pace = P.pace != nullptr && P.lag != 0u;
+  uint32_t *board = nullptr;
+  uint32_t my_slot = 0xffffffffu;
+  if (pace) {
+    board = P.pace + xcc_id() * PACE_SLOTS;
+    if (wave == 0u) {
+      my_slot = blockIdx.x >> 3;  // workgroups are dealt to the XCDs round-robin: distinct slots on a board
+      if (lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = 0u;
+    }
+  }
+  BoardView seen{~0ull, ~0ull};
+  bool have_seen = false, gave_up = false;
+  uint32_t round = 0;
+#ifdef ABFT_DBG_STAMPS
+  // [0] segment tables (seg_base, 16-bit offsets)  [1] barrier in front of a tile  [2] staging (loads, ECC, gathers,
+  // LDS writes)  [3] barrier behind it  [4] ordered adds  [5] y prologue  [6] y epilogue + fused product  [7] total
+  unsigned long long dbg_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  STAMP(t_begin);
+#endif
+  for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x, round++) {
+    const uint32_t out0 = g * ABFT_PANEL_ROWS;
+    double acc[RPT];
+    STAMP(t_p0);
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
+    }
+#ifdef ABFT_DBG_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    STAMP(t_p1);
+    STAMP_ADD(5, t_p0, t_p1);
+    for (uint32_t c = c0; c < c1; c++) {
+      STAMP(t_s0);
+      const uint32_t seg = g * P.npanels + c;
+      const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+      const uint32_t step = round * nsteps + (c - c0);
+      if (e0 == e1) {  // uniform
+        if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;
+        continue;
+      }
+      if (pace && wave == 0u) {
+        if (step >= P.lag && !gave_up) {
+          const uint32_t need = step + 1u - P.lag;
+          uint32_t m = have_seen ? board_min(seen) : 0u;
+          if (m < need) {
+            int it = 0;
+            for (; it < 1024 && m < need; it++) {
+              __builtin_amdgcn_s_sleep(4);
+              m = board_min(board_load(board, lane));
+            }
+            if (it == 1024) gave_up = true;  // ~1 ms and still short: stop pacing rather than stall again
+          }
+        }
+        seen = board_load(board, lane);  // for the next step: its latency runs beside this step's work
+        have_seen = true;
+      }
+      const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+      uint32_t gs[RPT], ge[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        const uint32_t r = (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+        gs[j] = e0 + ptr[r];
+        ge[j] = e0 + ptr[r + 1];
+      }
+#ifdef ABFT_DBG_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      STAMP(t_s1);
+      STAMP_ADD(0, t_s0, t_s1);
+#if ABFT_CFG_COO_PANEL_PREFETCH
+      // software pipeline inside a segment: tile k + 1's streaming loads go out right behind tile k's gathers and
+      // are in flight during its barrier and ordered adds (16 more registers per thread)
+      CooTileRegs<EPT> cur, nxt;
+      coo_issue_loads<MODE, EPT>(A, e0, min(e1, e0 + TILE), cur);
+#endif
+      for (uint32_t lo = e0; lo < e1;) {
+        const uint32_t hi = min(e1, lo + TILE);
+        STAMP(t_a);
+        __syncthreads();
+        STAMP(t_b);
+#if ABFT_CFG_COO_PANEL_PREFETCH
+        coo_consume<MODE, EPT>(A, x, ev, lo, hi, cur, s_prod, s_col, hi < e1, hi, min(e1, hi + TILE), nxt);
+        cur = nxt;
+#else
+        coo_stage<MODE, EPT>(A, x, ev, lo, hi, s_prod, s_col);
+#endif
+        STAMP(t_c);
+        __syncthreads();
+        STAMP(t_d);
+#ifdef ABFT_DBG_NOADDS  // timing-only build (wrong results): one LDS read per thread instead of the ordered adds
+        acc[0] += s_prod[threadIdx.x];
+#else
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+          const uint32_t a0 = max(gs[j], lo), a1 = min(ge[j], hi);
+          if (a0 < a1) {
+            double t = acc[j];
+            lds_ordered_add<ABFT_CFG_COO_PANEL_SHORT_SUMS>(A, ev, s_prod, s_col, a0 - lo, a1 - lo,
+                                                           out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x, lo, t);
+            acc[j] = t;
+          }
+        }
+#endif
+        STAMP(t_e);
+        STAMP_ADD(1, t_a, t_b);
+        STAMP_ADD(2, t_b, t_c);
+        STAMP_ADD(3, t_c, t_d);
+        STAMP_ADD(4, t_d, t_e);
+        lo = hi;
+      }
+      if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;  // plain store: into this XCD's L2
+    }
+    STAMP(t_q0);
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      if (o < A.n_out) {
+        y[o] = acc[j];
+        if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
+      }
+    }
+    STAMP(t_q1);
+    STAMP_ADD(6, t_q0, t_q1);
+  }
+  if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
+  // done: never holds anyone back, and the board is clean for the next launch
+  if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;
+#ifdef ABFT_DBG_STAMPS
+  if (threadIdx.x == 0 && P.debug) {
+    STAMP(t_end);
+    dbg_t[7] = t_end - t_begin;
+    for (int k = 0; k < 8; k++) atomicAdd(P.debug + (c0 > 0 ? 8 : 0) + k, dbg_t[k]);
+  }
+#endif
+}
+
+// wait until each of the four per-wave counts (LDS) has reached `want`
+__device__ __forceinline__ void pc_wait_all(const uint32_t *counts, uint32_t want) {
+  for (;;) {
+    const uint32_t a = __hip_atomic_load(counts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t b = __hip_atomic_load(counts + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t c = __hip_atomic_load(counts + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t d = __hip_atomic_load(counts + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (min(min(a, b), min(c, d)) >= want) return;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// ---- the COO panel kernel with the two halves of a tile's work on different waves (round 4) ----
+// Timing builds of spmv_coo_panels_kernel on configs[4] (sec7; gpurun_out/r4/c5_ab2.txt): streaming the elements alone
+// (no gathers, no sums) 84 us; with the ordered sums 146; with the gathers and no sums 186; everything 202 -- the
+// phases of a tile (stream, check, gather | barrier | sum | barrier) run one after the other inside a workgroup and
+// the 4 workgroups of a CU do not fill each other's gaps: the CU's gather path (~3 clocks per gathered lane) is
+// busy ~3/4 of the time.  Here a workgroup is 8 waves: waves 4-7 PRODUCE (stream a tile, check it, gather, write
+// products and columns into one of NB LDS buffers) and never sum, waves 0-3 CONSUME (the ordered sums of their 8
+// outputs per lane, exactly as before: same lanes, same order, same bits) and never touch global memory inside a
+// tile.  No workgroup barrier in the loop: two LDS counters (tiles filled x4, tiles summed x4) pace the two sides,
+// so the producers of a CU keep gathers in flight while its consumers sum.  Registers: the roles' needs do not
+// add up (tile registers on one side, sums and ranges on the other), 8 waves per SIMD.
+template <int MODE, int EPT, bool FUSE>
+__global__ __launch_bounds__(512, 8) void spmv_coo_pc_kernel(CooDev A, CsrPanels P, const double *__restrict__ x,
+                                                             double *__restrict__ y, EventRing ev, FuseOut fuse,
+                                                             uint32_t c0, uint32_t c1) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
+  constexpr uint32_t NB = 2;  // LDS buffers
+  __shared__ __attribute__((aligned(16))) double s_prod[NB][TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[NB][TILE];
+  // tiles filled by each producer wave / summed by each consumer wave (a wave may be a tile ahead of its peers: one
+  // shared count would let three fast waves stand in for a slow one)
+  __shared__ __attribute__((aligned(16))) uint32_t s_full[4], s_done[4];
+  __shared__ double s_w[8];
+  __shared__ MovedNote s_notes[4][PC_NOTES];  // per consumer wave: products whose column names another output (cold)
+  __shared__ uint32_t s_ncount[4];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool producer = wave >= 4u;
+  const uint32_t tid = threadIdx.x & 255u;  // index inside the role
+  if (threadIdx.x < 4u) { s_full[threadIdx.x] = 0u; s_done[threadIdx.x] = 0u; s_ncount[threadIdx.x] = 0u; }
+  __syncthreads();
+  const uint32_t nsteps = c1 - c0;
+  const bool pace = P.pace != nullptr && P.lag != 0u;
+  uint32_t *board = nullptr;
+  uint32_t my_slot = 0xffffffffu;
+  if (pace) {
+    board = P.pace + xcc_id() * PACE_SLOTS;
+    if (wave == 4u) {
+      my_slot = blockIdx.x >> 3;
+      if (lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = 0u;
+    }
+  }
+  BoardView seen{~0ull, ~0ull};
+  bool have_seen = false, gave_up = false;
+  uint32_t tile_no = 0;  // tiles of this workgroup so far (both roles count alike)
+  uint32_t round = 0;
+  double dsum = 0.0;
+  for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x, round++) {
+    const uint32_t out0 = g * ABFT_PANEL_ROWS;
+    if (producer) {
+      for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t seg = g * P.npanels + c;
+        const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+        const uint32_t step = round * nsteps + (c - c0);
+        if (e0 != e1) {  // uniform
+          if (pace && wave == 4u) {
+            if (step >= P.lag && !gave_up) {
+              const uint32_t need = step + 1u - P.lag;
+              uint32_t m = have_seen ? board_min(seen) : 0u;
+              if (m < need) {
+                int it = 0;
+                for (; it < 1024 && m < need; it++) {
+                  __builtin_amdgcn_s_sleep(4);
+                  m = board_min(board_load(board, lane));
+                }
+                if (it == 1024) gave_up = true;
+              }
+            }
+            seen = board_load(board, lane);
+            have_seen = true;
+          }
+          for (uint32_t lo = e0; lo < e1; tile_no++) {
+            const uint32_t hi = min(e1, lo + TILE);
+            const uint32_t b = tile_no % NB;
+            CooTileRegs<EPT> t;
+            // the streaming loads do not need the buffer: issue them, THEN wait for the consumers to have left it
+#pragma unroll
+            for (int k = 0; k < EPT; k++) {
+              const uint32_t j = lo + tid + (uint32_t)k * ABFT_BLOCK;
+              t.e[k] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
+            }
+            if (tile_no >= NB) pc_wait_all(s_done, tile_no - NB + 1u);  // every consumer wave has summed tile tile_no - NB
+            coo_consume_pc<MODE, EPT>(A, x, ev, lo, hi, t, s_prod[b], s_col[b], tid);
+            // this wave's LDS writes have landed: count it in
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0u) __hip_atomic_store(&s_full[wave - 4u], tile_no + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            lo = hi;
+          }
+        }
+        if (pace && wave == 4u && lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;
+      }
+    } else {
+      double acc[RPT];
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + tid;
+        acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
+      }
+      for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t seg = g * P.npanels + c;
+        const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+        if (e0 == e1) continue;  // uniform
+        const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+        uint32_t gse[RPT];  // an output's range inside the segment, both ends relative to e0 in 16 bits each (a segment holds < 65536 elements)
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+          const uint32_t r = (uint32_t)j * ABFT_BLOCK + tid;
+          gse[j] = (uint32_t)ptr[r] | ((uint32_t)ptr[r + 1] << 16);
+        }
+        for (uint32_t lo = e0; lo < e1; tile_no++) {
+          const uint32_t hi = min(e1, lo + TILE);
+          const uint32_t b = tile_no % NB;
+          pc_wait_all(s_full, tile_no + 1u);  // every producer wave has filled tile tile_no
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+          for (int j = 0; j < RPT; j++) {
+            const uint32_t a0 = max(e0 + (gse[j] & 0xffffu), lo), a1 = min(e0 + (gse[j] >> 16), hi);
+            if (a0 < a1) {
+              double tt = acc[j];
+              lds_ordered_add_pc(s_prod[b], s_col[b], a0 - lo, a1 - lo, out0 + (uint32_t)j * ABFT_BLOCK + tid, lo, tt,
+                                 &s_ncount[wave], s_notes[wave]);
+              acc[j] = tt;
+            }
+          }
+          // this wave's LDS reads have returned: the buffer may be refilled
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0u) __hip_atomic_store(&s_done[wave], tile_no + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          lo = hi;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RPT; j++) {
+        const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + tid;
+        if (o < A.n_out) {
+          y[o] = acc[j];
+          if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
+        }
+      }
+      // cold: this wave's noted strangers go to the fix-up's queue (its own LDS list: no other wave touches it)
+      const uint32_t notes = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ncount[wave]);
+      if (__builtin_expect(notes != 0u, 0)) {
+        for (uint32_t k = lane; k < min(notes, PC_NOTES); k += 64u)
+          coo_push_moved(A, ev, s_notes[wave][k].j, s_notes[wave][k].col, s_notes[wave][k].prod);
+        if (notes > PC_NOTES && lane == 0u) push_event(ev, ABFT_EV_MOVED_OVERFLOW, PC_NOTES, 0, FMT_COO);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0u) s_ncount[wave] = 0u;
+      }
+    }
+  }
+  if (FUSE) {  // block_sum over the consumer waves (0-3: the lanes and order of the one-role kernel's partial)
+    const double v = wave_sum(dsum);
+    if (lane == 63u) s_w[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) fuse.partials[blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+  }
+  if (pace && wave == 4u && lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;
+}
+
+template <int MODE> static int coo_pc_occupancy() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_coo_pc_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>, 512, 0) != hipSuccess || n < 1)
+    n = 1;
+  return n > 8 ? 8 : n;
+}
+int spmv_coo_pc_blocks_per_cu(int mode) {
+  switch (mode) {
+    case MODE_NONE: return coo_pc_occupancy<MODE_NONE>();
+    case MODE_SED: return coo_pc_occupancy<MODE_SED>();
+    case MODE_SEC7: return coo_pc_occupancy<MODE_SEC7>();
+    case MODE_SEC8: return coo_pc_occupancy<MODE_SEC8>();
+    default: return coo_pc_occupancy<MODE_SECDED>();
+  }
+}
+
+template <int MODE>
+static hipError_t launch_coo_pc_mode(const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
+                                     const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+  if (fuse)
+    hipLaunchKernelGGL((spmv_coo_pc_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>), dim3(grid), dim3(512), 0, s, A, P, x, y, ev,
+                       *fuse, c0, c1);
+  else
+    hipLaunchKernelGGL((spmv_coo_pc_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, false>), dim3(grid), dim3(512), 0, s, A, P, x, y, ev,
+                       FuseOut{}, c0, c1);
+  return hipGetLastError();
+}
+
+// (constraints mode keeps the one-role kernel: its checks need the successor table in the staging phase)
+hipError_t launch_spmv_coo_pc(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
+                              const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s) {
+  if (P.ngroups == 0) return hipSuccess;
+  if (chunk == 0 || chunk > P.npanels) chunk = P.npanels;
+  for (uint32_t c0 = 0; c0 < P.npanels; c0 += chunk) {
+    const uint32_t c1 = c0 + chunk < P.npanels ? c0 + chunk : P.npanels;
+    const FuseOut *f = c1 == P.npanels ? fuse : nullptr;
+    hipError_t e;
+    switch (mode) {
+      case MODE_NONE: e = launch_coo_pc_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SED: e = launch_coo_pc_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC7: e = launch_coo_pc_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC8: e = launch_coo_pc_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SECDED: e = launch_coo_pc_mode<MODE_SECDED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int MODE>
+static hipError_t launch_coo_panels_mode(const CooDev &A, const CsrPanels &P, const double *x, double *y,
+                                         EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t c0,
+                                         uint32_t c1, hipStream_t s) {
+  if (fuse)
+    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
+                       P, x, y, ev, *fuse, c0, c1);
+  else
+    hipLaunchKernelGGL((spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A,
+                       P, x, y, ev, FuseOut{}, c0, c1);
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_coo_panels(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y,
+                                  EventRing ev, const FuseOut *fuse, uint32_t grid, uint32_t chunk,
+                                  hipStream_t s) {
+  if (P.ngroups == 0) return hipSuccess;
+  if (chunk == 0 || chunk > P.npanels) chunk = P.npanels;
+  for (uint32_t c0 = 0; c0 < P.npanels; c0 += chunk) {
+    const uint32_t c1 = c0 + chunk < P.npanels ? c0 + chunk : P.npanels;
+    const FuseOut *f = c1 == P.npanels ? fuse : nullptr;
+    hipError_t e;
+    switch (mode) {
+      case MODE_NONE: e = launch_coo_panels_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_CONSTRAINTS: e = launch_coo_panels_mode<MODE_CONSTRAINTS>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SED: e = launch_coo_panels_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC7: e = launch_coo_panels_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC8: e = launch_coo_panels_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SECDED: e = launch_coo_panels_mode<MODE_SECDED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int MODE> static int coo_panels_occupancy() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_coo_panels_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>, ABFT_BLOCK, 0) !=
+          hipSuccess || n < 1)
+    n = 1;
+  return n > 8 ? 8 : n;
+}
+// workgroups of the COO panel kernel a CU holds at once (a paced launch needs all of its workgroups resident)
+int spmv_coo_panels_blocks_per_cu(int mode) {
+  switch (mode) {
+    case MODE_NONE: return coo_panels_occupancy<MODE_NONE>();
+    case MODE_CONSTRAINTS: return coo_panels_occupancy<MODE_CONSTRAINTS>();
+    case MODE_SED: return coo_panels_occupancy<MODE_SED>();
+    case MODE_SEC7: return coo_panels_occupancy<MODE_SEC7>();
+    case MODE_SEC8: return coo_panels_occupancy<MODE_SEC8>();
+    default: return coo_panels_occupancy<MODE_SECDED>();
+  }
+}
+
+template <int MODE>
+static hipError_t launch_spmv_coo_mode(const CooDev &A, const double *x, double *y, EventRing ev,
+                                       const FuseOut *fuse, hipStream_t s) {
+  if (fuse) {
+    hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT, true>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, *fuse);
+  } else
+    hipLaunchKernelGGL((spmv_coo_kernel<MODE, ABFT_COO_EPT, false>), dim3(A.nblk), dim3(ABFT_BLOCK), 0, s, A,
+                       x, y, ev, FuseOut{});
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_coo(int mode, const CooDev &A, const double *x, double *y, EventRing ev,
+                           const FuseOut *fuse, hipStream_t s) {
+  if (A.nblk == 0) return hipSuccess;
+  switch (mode) {
+    case MODE_NONE: return launch_spmv_coo_mode<MODE_NONE>(A, x, y, ev, fuse, s);
+    case MODE_CONSTRAINTS: return launch_spmv_coo_mode<MODE_CONSTRAINTS>(A, x, y, ev, fuse, s);
+    case MODE_SED: return launch_spmv_coo_mode<MODE_SED>(A, x, y, ev, fuse, s);
+    case MODE_SEC7: return launch_spmv_coo_mode<MODE_SEC7>(A, x, y, ev, fuse, s);
+    case MODE_SEC8: return launch_spmv_coo_mode<MODE_SEC8>(A, x, y, ev, fuse, s);
+    case MODE_SECDED: return launch_spmv_coo_mode<MODE_SECDED>(A, x, y, ev, fuse, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ------------------------------------------------------------ sweep-layout SpMV --
 
 // Sweep-layout SpMV (CSR; see SweepLayout).  Stages a segment tile by tile through LDS with
 // the same branch-free load phase as the streaming kernel (ECC in registers, cold path out

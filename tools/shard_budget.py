@@ -38,7 +38,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-LINK_GBPS, EFF, T_WINDOW_US = 153.0, 0.7, 9.0
+# T_WINDOW_US: measured between two contexts on ONE device (a lower bound for two devices: no xGMI hop in it);
+# 14 us through shared host memory (round 2).  Both bounds are printed.
+LINK_GBPS, EFF, T_WINDOW_US, T_WINDOW_HOST_US = 153.0, 0.7, 9.0, 14.0
 
 
 def shard(spec, G, k):
@@ -92,8 +94,13 @@ def time_shard(mode, pin, lrows, vals, n_loc, n_pad, slot, k, iters=60, allreduc
             capi.check(L.abft_hip_peer_board_attach_device(h, boards, 0, 1, 5.0))
         capi.check(L.abft_hip_peer_board_fuse(h, 1))  # in the tails of the reductions, as host/HIPContext.cpp runs them
 
+    three = os.environ.get("ABFT_CG_TAIL") == "0"  # rounds 2-3: fold, calc_r, calc_px as three launches
+
     def it(parity):
         cur, nxt, pw = base + 16 * parity, base + 16 * (1 - parity), base + 32
+        if not three:  # as host/HIPContext.cpp runs it since round 4: everything behind the SpMV in one launch
+            capi.check(L.abft_hip_cg_iteration_dev(h, A.h, pfull.h, k * slot, capi.PART_ALL, x.h, r.h, p.h, w.h, cur, pw, nxt))
+            return
         capi.check(L.abft_hip_spmv_dot_dev(h, A.h, pfull.h, w.h, k * slot, pw))
         capi.check(L.abft_hip_calc_xr_ratio_dev(h, x.h, r.h, p.h, w.h, cur, pw, nxt))
         capi.check(L.abft_hip_calc_p_ratio_dev(h, p.h, r.h, nxt, cur))
