@@ -125,6 +125,7 @@ struct abft_hip_matrix {
   double *fuse_partials = nullptr;  // FuseOut buffer (square matrices)
   bool use_panels = false;          // panel layout chosen at create time
   bool coo_pc = false;              // COO panel layout run by spmv_coo_pc_kernel (producer / consumer waves)
+  bool coo_lean = false;            // ... or by spmv_coo_lean_kernel (cold paths out of the hot loop)
   CsrPanels panels{};
   uint32_t panel_grid = 0;          // workgroups of the panel kernel
   uint32_t panel_chunk = 0;         // panels per launch (0 = all)
@@ -875,6 +876,9 @@ static int create_csr(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     m->panels.seg_ptr = d_segptr;
     m->panels.ngroups = pb.ngroups;
     m->panels.npanels = pb.npanels;
+    m->panels.width = pb.width;
+    m->panels.xpf = 0;
+    if (const char *e = getenv("ABFT_HIP_PANEL_XPF")) m->panels.xpf = (uint32_t)std::max(0L, atol(e));
     m->panels.debug = nullptr;
     if (getenv("ABFT_HIP_PANEL_DEBUG")) {  // phase clocks of a -DABFT_DBG_STAMPS build, printed when the matrix is destroyed
       unsigned long long *d_dbg = nullptr;
@@ -983,6 +987,9 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     m->panels.seg_ptr = d_segptr;
     m->panels.ngroups = pb.ngroups;
     m->panels.npanels = pb.npanels;
+    m->panels.width = pb.width;
+    m->panels.xpf = 0;
+    if (const char *e = getenv("ABFT_HIP_PANEL_XPF")) m->panels.xpf = (uint32_t)std::max(0L, atol(e));
     m->panels.debug = nullptr;
     if (getenv("ABFT_HIP_PANEL_DEBUG")) {  // phase clocks of a -DABFT_DBG_STAMPS build, printed when the matrix is destroyed
       unsigned long long *d_dbg = nullptr;
@@ -1038,9 +1045,12 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
     if (format == ABFT_FMT_COO && mode != ABFT_MODE_CONSTRAINTS) {
       const char *e = getenv("ABFT_HIP_COO_PC");
       m->coo_pc = e && strcmp(e, "0") != 0;
+      e = getenv("ABFT_HIP_COO_LEAN");
+      m->coo_lean = !m->coo_pc && e && strcmp(e, "0") != 0;
     }
     const uint32_t resident = (uint32_t)(format != ABFT_FMT_COO ? 0 : (m->coo_pc ? spmv_coo_pc_blocks_per_cu(mode)
-                                                                                : spmv_coo_panels_blocks_per_cu(mode)) * ctx->num_cus);
+                                                                      : m->coo_lean ? spmv_coo_lean_blocks_per_cu(mode)
+                                                                                    : spmv_coo_panels_blocks_per_cu(mode)) * ctx->num_cus);
     uint32_t lag = (format == ABFT_FMT_COO && m->panels.ngroups <= resident && !getenv("ABFT_HIP_PANEL_CHUNK")) ? 2u : 0u;
     if (const char *e = getenv("ABFT_HIP_PANEL_LAG")) lag = (uint32_t)std::max(0L, atol(e));
     if (format == ABFT_FMT_COO && lag > 0) {
@@ -2100,6 +2110,9 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
       if (mat->coo_pc)
         HIPCHK(launch_spmv_coo_pc(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
                                   do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
+      else if (mat->coo_lean)
+        HIPCHK(launch_spmv_coo_lean(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
+                                    do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));
       else
         HIPCHK(launch_spmv_coo_panels(mat->mode, mat->coo, mat->panels, vec->d, result->d, ctx->ring,
                                       do_fuse ? &fuse : nullptr, mat->panel_grid, mat->panel_chunk, ctx->stream));

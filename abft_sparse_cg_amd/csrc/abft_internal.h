@@ -45,6 +45,8 @@ struct CsrPanels {
   unsigned long long *debug;  // optional (ABFT_HIP_PANEL_DEBUG, -DABFT_DBG_STAMPS builds): 2 x 8 phase clocks, first / later launches
   uint32_t *pace;             // COO panel kernel run as ONE launch over all panels: a progress board per XCD (as SweepLayout), else NULL
   uint32_t lag;               // workgroups of an XCD stay within `lag` panels of its slowest; 0: no pacing
+  uint32_t width;             // gather indices per panel
+  uint32_t xpf;               // COO panel kernel: entering a panel, the workgroups of an XCD touch the NEXT panel's lines of x (into that XCD's L2)
 };
 // Sweep layout: the panel layout's successor (same idea: (output group, gather-index panel)
 // segments, outputs' additions in the caller's order) run as ONE persistent launch:
@@ -155,6 +157,12 @@ struct CooDev {
 #endif
 #ifndef ABFT_CFG_COO_PANEL_EPT
 #define ABFT_CFG_COO_PANEL_EPT 4  // 16-byte elements per thread per tile of the COO panel kernel
+#endif
+#ifndef ABFT_CFG_COO_LEAN_WAVES
+#define ABFT_CFG_COO_LEAN_WAVES 8  // register budget of spmv_coo_lean_kernel, in waves per SIMD (8: 64 VGPRs)
+#endif
+#ifndef ABFT_CFG_COO_PANEL_XPF_AHEAD
+#define ABFT_CFG_COO_PANEL_XPF_AHEAD 1  // the x prefetch of the COO panel kernel runs this many panels ahead
 #endif
 #ifndef ABFT_CFG_COO_PANEL_PREFETCH
 #define ABFT_CFG_COO_PANEL_PREFETCH 0  // COO panel kernel: the next tile's streaming loads issued behind this tile's gathers
@@ -335,6 +343,9 @@ struct TailArgs {
 };
 int spmv_coo_panels_blocks_per_cu(int mode);
 int spmv_coo_pc_blocks_per_cu(int mode);
+int spmv_coo_lean_blocks_per_cu(int mode);
+hipError_t launch_spmv_coo_lean(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
+                                const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
 hipError_t launch_spmv_coo_pc(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
                               const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
 int cg_tail_blocks_per_cu(bool vec2);

@@ -1313,6 +1313,24 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
         gs[j] = e0 + ptr[r];
         ge[j] = e0 + ptr[r + 1];
       }
+      // x prefetch: every gather of a tile waits for the slowest of its 1024, and 4-7 % of them miss the XCD's L2
+      // (each line of x must come into each L2 once per SpMV: 1.05 M of config 5's 26 M gathers, plus re-fetches) --
+      // so EVERY tile pays a miss's latency.  Entering panel c the workgroups of an XCD (slot = blockIdx / 8, dealt
+      // round-robin) share out the lines of panel c + AHEAD and touch one word of each: one extra load per thread, in
+      // flight beside the first tile's own loads, its value unused.
+      double xpf_v = 0.0;
+      bool xpf_on = false;
+      if (P.xpf) {
+        const uint32_t cn = c + (uint32_t)ABFT_CFG_COO_PANEL_XPF_AHEAD;
+        if (cn < P.npanels) {
+          const uint32_t lines = (P.width + 15u) / 16u, nwg = (gridDim.x + 7u) / 8u;
+          const uint32_t per = (lines + nwg - 1u) / nwg;
+          const uint32_t line = (blockIdx.x >> 3) * per + threadIdx.x;
+          const uint64_t row = (uint64_t)cn * P.width + (uint64_t)line * 16u;
+          xpf_on = threadIdx.x < per && line < lines && row < A.n_in;
+          if (xpf_on) xpf_v = gather_load(x + row);
+        }
+      }
 #ifdef ABFT_DBG_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -1359,6 +1377,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
         STAMP_ADD(4, t_d, t_e);
         lo = hi;
       }
+      if (xpf_on) asm volatile("" ::"v"(xpf_v));  // (keeps the prefetch load; long since returned)
       if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;  // plain store: into this XCD's L2
     }
     STAMP(t_q0);
@@ -1383,6 +1402,177 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
     for (int k = 0; k < 8; k++) atomicAdd(P.debug + (c0 > 0 ? 8 : 0) + k, dbg_t[k]);
   }
 #endif
+}
+
+// ---- the COO panel kernel with its cold paths out of the hot loop (round 4) ----
+// spmv_coo_panels_kernel needs 86-89 VGPRs, of which ~30 are the price of two out-of-line calls inside its hot
+// sections (the ECC repair in the staging phase, the queueing of a stranger in the summing phase: a call costs its
+// callee's registers on top of everything live across it).  Here both are deferred -- a failed check is staged as "no
+// product" and repaired behind the LDS writes (coo_consume_pc), a stranger is noted in a per-wave LDS list and queued
+// when the group is done (lds_ordered_add_pc) -- so that the kernel fits the register budget of 8 workgroups per CU
+// (with 4 outputs per thread: -DABFT_CFG_PANEL_RPT=4), i.e. twice the waves to keep gathers in flight.  Same lanes,
+// same order of additions, same bits.
+template <int MODE, int EPT, bool FUSE>
+__global__ __launch_bounds__(ABFT_BLOCK, ABFT_CFG_COO_LEAN_WAVES) void spmv_coo_lean_kernel(CooDev A, CsrPanels P,
+                                                                     const double *__restrict__ x,
+                                                                     double *__restrict__ y, EventRing ev,
+                                                                     FuseOut fuse, uint32_t c0, uint32_t c1) {
+  constexpr uint32_t TILE = ABFT_BLOCK * EPT;
+  constexpr int RPT = ABFT_PANEL_ROWS_PER_THREAD;
+  __shared__ __attribute__((aligned(16))) double s_prod[TILE];
+  __shared__ __attribute__((aligned(16))) uint32_t s_col[TILE];
+  __shared__ MovedNote s_notes[4][PC_NOTES];
+  __shared__ uint32_t s_ncount[4];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (threadIdx.x < 4u) s_ncount[threadIdx.x] = 0u;
+  const uint32_t nsteps = c1 - c0;
+  const bool pace = P.pace != nullptr && P.lag != 0u;
+  uint32_t *board = nullptr;
+  uint32_t my_slot = 0xffffffffu;
+  if (pace) {
+    board = P.pace + xcc_id() * PACE_SLOTS;
+    if (wave == 0u) {
+      my_slot = blockIdx.x >> 3;
+      if (lane == 0u && my_slot < PACE_SLOTS) board[my_slot] = 0u;
+    }
+  }
+  BoardView seen{~0ull, ~0ull};
+  bool have_seen = false, gave_up = false;
+  uint32_t round = 0;
+  double dsum = 0.0;
+  for (uint32_t g = blockIdx.x; g < P.ngroups; g += gridDim.x, round++) {
+    const uint32_t out0 = g * ABFT_PANEL_ROWS;
+    double acc[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      acc[j] = (c0 > 0 && o < A.n_out) ? y[o] : 0.0;
+    }
+    for (uint32_t c = c0; c < c1; c++) {
+      const uint32_t seg = g * P.npanels + c;
+      const uint32_t e0 = P.seg_base[seg], e1 = P.seg_base[seg + 1];
+      const uint32_t step = round * nsteps + (c - c0);
+      if (e0 != e1) {  // uniform
+        if (pace && wave == 0u) {
+          if (step >= P.lag && !gave_up) {
+            const uint32_t need = step + 1u - P.lag;
+            uint32_t m = have_seen ? board_min(seen) : 0u;
+            if (m < need) {
+              int it = 0;
+              for (; it < 1024 && m < need; it++) {
+                __builtin_amdgcn_s_sleep(4);
+                m = board_min(board_load(board, lane));
+              }
+              if (it == 1024) gave_up = true;
+            }
+          }
+          seen = board_load(board, lane);
+          have_seen = true;
+        }
+        const uint16_t *ptr = P.seg_ptr + (size_t)seg * (ABFT_PANEL_ROWS + 1);
+        uint32_t gse[RPT];  // an output's range inside the segment: both ends relative to e0, 16 bits each
+#pragma unroll
+        for (int j = 0; j < RPT; j++) {
+          const uint32_t r = (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+          gse[j] = (uint32_t)ptr[r] | ((uint32_t)ptr[r + 1] << 16);
+        }
+        for (uint32_t lo = e0; lo < e1;) {
+          const uint32_t hi = min(e1, lo + TILE);
+          CooTileRegs<EPT> t;
+#pragma unroll
+          for (int k = 0; k < EPT; k++) {
+            const uint32_t j = lo + threadIdx.x + (uint32_t)k * ABFT_BLOCK;
+            t.e[k] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
+          }
+          __syncthreads();  // (the previous tile's sums have left the buffer)
+          coo_consume_pc<MODE, EPT>(A, x, ev, lo, hi, t, s_prod, s_col, threadIdx.x);
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < RPT; j++) {
+            const uint32_t a0 = max(e0 + (gse[j] & 0xffffu), lo), a1 = min(e0 + (gse[j] >> 16), hi);
+            if (a0 < a1) {
+              double tt = acc[j];
+              lds_ordered_add_pc(s_prod, s_col, a0 - lo, a1 - lo, out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x, lo, tt,
+                                 &s_ncount[wave], s_notes[wave]);
+              acc[j] = tt;
+            }
+          }
+          lo = hi;
+        }
+      }
+      if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;
+    }
+#pragma unroll
+    for (int j = 0; j < RPT; j++) {
+      const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
+      if (o < A.n_out) {
+        y[o] = acc[j];
+        if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
+      }
+    }
+    // cold: this wave's noted strangers go to the fix-up's queue
+    const uint32_t notes = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_ncount[wave]);
+    if (__builtin_expect(notes != 0u, 0)) {
+      for (uint32_t k = lane; k < min(notes, PC_NOTES); k += 64u)
+        coo_push_moved(A, ev, s_notes[wave][k].j, s_notes[wave][k].col, s_notes[wave][k].prod);
+      if (notes > PC_NOTES && lane == 0u) push_event(ev, ABFT_EV_MOVED_OVERFLOW, PC_NOTES, 0, FMT_COO);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0u) s_ncount[wave] = 0u;
+    }
+  }
+  if (FUSE) fused_dot_finish(dsum, fuse, blockIdx.x);
+  if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = 0xffffffffu;
+}
+
+template <int MODE> static int coo_lean_occupancy() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, spmv_coo_lean_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>, ABFT_BLOCK, 0) !=
+          hipSuccess || n < 1)
+    n = 1;
+  return n > 8 ? 8 : n;
+}
+int spmv_coo_lean_blocks_per_cu(int mode) {
+  switch (mode) {
+    case MODE_NONE: return coo_lean_occupancy<MODE_NONE>();
+    case MODE_SED: return coo_lean_occupancy<MODE_SED>();
+    case MODE_SEC7: return coo_lean_occupancy<MODE_SEC7>();
+    case MODE_SEC8: return coo_lean_occupancy<MODE_SEC8>();
+    default: return coo_lean_occupancy<MODE_SECDED>();
+  }
+}
+
+template <int MODE>
+static hipError_t launch_coo_lean_mode(const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
+                                       const FuseOut *fuse, uint32_t grid, uint32_t c0, uint32_t c1, hipStream_t s) {
+  if (fuse)
+    hipLaunchKernelGGL((spmv_coo_lean_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, true>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A, P, x, y,
+                       ev, *fuse, c0, c1);
+  else
+    hipLaunchKernelGGL((spmv_coo_lean_kernel<MODE, ABFT_CFG_COO_PANEL_EPT, false>), dim3(grid), dim3(ABFT_BLOCK), 0, s, A, P, x, y,
+                       ev, FuseOut{}, c0, c1);
+  return hipGetLastError();
+}
+
+hipError_t launch_spmv_coo_lean(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
+                                const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s) {
+  if (P.ngroups == 0) return hipSuccess;
+  if (chunk == 0 || chunk > P.npanels) chunk = P.npanels;
+  for (uint32_t c0 = 0; c0 < P.npanels; c0 += chunk) {
+    const uint32_t c1 = c0 + chunk < P.npanels ? c0 + chunk : P.npanels;
+    const FuseOut *f = c1 == P.npanels ? fuse : nullptr;
+    hipError_t e;
+    switch (mode) {
+      case MODE_NONE: e = launch_coo_lean_mode<MODE_NONE>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SED: e = launch_coo_lean_mode<MODE_SED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC7: e = launch_coo_lean_mode<MODE_SEC7>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SEC8: e = launch_coo_lean_mode<MODE_SEC8>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      case MODE_SECDED: e = launch_coo_lean_mode<MODE_SECDED>(A, P, x, y, ev, f, grid, c0, c1, s); break;
+      default: return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
 }
 
 // wait until each of the four per-wave counts (LDS) has reached `want`
