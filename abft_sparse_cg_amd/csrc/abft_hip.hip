@@ -55,6 +55,7 @@ struct abft_hip_ctx {
   uint32_t *tail_sync = nullptr;  // cg_tail_kernel's hand-off words (device, zero between launches)
   bool tail_enabled = true;       // ABFT_HIP_TAIL=0: the iteration's tail as its three kernels
   int tail_cap[2] = {-1, -1};     // workgroups of cg_tail_kernel<1> / <2> that are resident at once (asked once)
+  int sharers = 1;                // processes that run this library on this device at the same time (abft_hip_set_sharers)
   uint32_t seq = 0;            // last sequence number handed to a reduction
   bool spin_wait = true;       // wait for scalars by polling the pinned slot
   HostSlot *host_slot = nullptr;      // pinned, device-visible
@@ -2191,6 +2192,12 @@ extern "C" int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *ma
   return spmv_common(ctx, mat, vec, result, vec_offset, dev_result, part);
 }
 
+extern "C" int abft_hip_set_sharers(abft_hip_ctx *ctx, int processes) {
+  if (!ctx || processes < 1) return set_err(ABFT_ERR_INVALID, "set_sharers: bad argument");
+  ctx->sharers = processes;
+  return ABFT_OK;
+}
+
 // ---- one CG iteration behind its exchange (cg.cpp:97-112), scalars on the device ----------------
 // spmv(A, vec, w) [a part of it] + p.w, then r -= alpha w, r.r, x += alpha p, p = r + beta p with
 // alpha = rr / p.w and beta = rr_new / rr formed on the device.  The same results, bit for bit, as
@@ -2213,14 +2220,22 @@ extern "C" int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat
   const ReduceOut o = reduce_out(ctx, dev_rr_new, false);
   const int n = x->n;
   const bool vec2 = (((uintptr_t)x->d | (uintptr_t)r->d | (uintptr_t)p->d | (uintptr_t)w->d) & 15u) == 0;  // (as the three kernels decide)
-  bool merged = hold.held && ctx->tail_enabled && ctx->defer_enabled && n > 0 && !(x->root ? x->root : x)->exposed &&
+  // (worth it while launch boundaries and reduction tails outweigh the second read of r that the one launch costs --
+  // phase C re-reads what phase B wrote, 8 n bytes: cg-csr --bench on one GPU, it/s with one launch / three kernels:
+  // 1 M rows 24 400 / 22 400; configs[3]'s 1/8 shard (524 288 rows) 9 000 / 8 900; its 4.2 M rows 1 407 / 1 400; config
+  // 2's 10 M rows 3 930 / 4 160 -- gpurun_out/r4/tail_ab1.txt; hence up to 2^22 rows)
+  bool merged = hold.held && ctx->tail_enabled && ctx->defer_enabled && n > 0 && n <= (1 << 22) && !(x->root ? x->root : x)->exposed &&
                 disjoint(x, r) && disjoint(x, p) && disjoint(x, w) && disjoint(r, p) && disjoint(r, w) && disjoint(p, w);
   uint32_t grid = 0;
   const uint32_t nbv = (uint32_t)reduce_blocks(n);
   if (merged) {
     int &cap = ctx->tail_cap[vec2 ? 1 : 0];
     if (cap < 0) cap = cg_tail_blocks_per_cu(vec2) * ctx->num_cus;
-    grid = std::min<uint32_t>((nbv + 3u) / 4u, (uint32_t)std::max(cap, 0));
+    // the workgroups wait for each other (and, across ranks, for the peers' launches): ALL of them must be resident.
+    // Several processes on one device (tests: ranks sharing the one GPU) each get their share of it, less a half
+    // for whatever else those processes have in flight.
+    const int mine = ctx->sharers > 1 ? cap / (2 * ctx->sharers) : cap;
+    grid = std::min<uint32_t>((nbv + 3u) / 4u, (uint32_t)std::max(mine, 0));
     merged = grid > 0;
   }
   if (!merged) {

@@ -106,6 +106,18 @@ void HIPContextBase::setup_peer_board()
   one_node_ = size <= 64;
   for (int r = 0; r < size; r++)
     one_node_ = one_node_ && !memcmp(&hosts[(size_t)r * sizeof(host)], host, sizeof(host));
+  // ranks that share this rank's GPU (tests run several on the one GPU): kernels that wait inside size their grids
+  // for that share (abft_hip_set_sharers)
+  {
+    int device = comm_->local_rank();
+    if (const char *e = getenv("ABFT_HIP_DEVICE")) device = atoi(e);
+    std::vector<int> devices((size_t)size);
+    comm_->allgather(&device, sizeof(device), devices.data());
+    int sharers = 0;
+    for (int r = 0; r < size; r++)
+      sharers += devices[r] == device && !memcmp(&hosts[(size_t)r * sizeof(host)], host, sizeof(host));
+    check(abft_hip_set_sharers(ctx_, sharers > 0 ? sharers : 1), "abft_hip_set_sharers");
+  }
   const char *env = getenv("ABFT_COMM_ALLREDUCE");
   const bool any = !env || !strcmp(env, "auto");
   const bool want_ipc = any || !strcmp(env, "ipc"), want_host = any || !strcmp(env, "board");

@@ -356,6 +356,12 @@ int abft_hip_matrix_panels(abft_hip_matrix *mat, int *npanels, int *width);
 int abft_hip_spmv_dot_range_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                                 abft_hip_vector *result, int vec_offset, double *dev_result, int c0, int c1);
 
+/* `processes` processes drive this library on the context's device at the same time (ranks sharing one GPU:
+ * tests).  Launches whose workgroups wait for each other inside the kernel (abft_hip_cg_iteration_dev's one-launch
+ * tail) then size their grids for that share of the device, so that every process's workgroups are resident
+ * together.  Default 1: one process per GPU. */
+int abft_hip_set_sharers(abft_hip_ctx *ctx, int processes);
+
 /* One CG iteration behind its exchange, scalars on the device (reference loop cg.cpp:97-112):
  *   w = A vec [part: ABFT_PART_ALL, or ABFT_PART_BOUNDARY after an ABFT_PART_INTERIOR call],
  *   dev_pw = {vec[vec_offset..] . w, events};  alpha = dev_rr[0] / dev_pw[0];
@@ -364,8 +370,9 @@ int abft_hip_spmv_dot_range_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const a
  * Bit for bit what abft_hip_spmv_dot_part_dev + abft_hip_calc_xr_ratio_dev + abft_hip_calc_p_ratio_dev
  * leave behind (with abft_hip_peer_board_fuse the two scalars arrive summed over the ranks, as there),
  * but everything behind the SpMV -- the fold of the fused product, the r half, the x / p half and the
- * two board all-reduces -- is ONE launch of co-resident workgroups where that applies (x private to
- * the library and no operand aliasing another; ABFT_HIP_TAIL=0 keeps the three kernels).  p is the
+ * two board all-reduces -- is ONE launch of co-resident workgroups where that applies (vectors of at most
+ * 2^22 entries -- beyond that the three kernels are faster --, x private to the library and no operand
+ * aliasing another; ABFT_HIP_TAIL=0 keeps the three kernels).  p is the
  * caller's view of vec's slot (the vector the SpMV read).  Enqueue-only: capturable. */
 int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec, int vec_offset,
                               int part, abft_hip_vector *x, abft_hip_vector *r, abft_hip_vector *p,
