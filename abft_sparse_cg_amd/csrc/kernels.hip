@@ -267,8 +267,11 @@ __device__ __forceinline__ unsigned long long peer_check_word(unsigned long long
 // `seq_given` != 0: the caller names the sequence number and says whether this call leaves it in the counter
 // (cg_tail_kernel: two all-reduces in one launch, run by different workgroups -- a counter bumped by the first
 // would sit dirty in that workgroup's L2 when the second reads it)
+// `publish` false: this workgroup only READS the ranks' slots (every workgroup of cg_tail_kernel forms the sum itself;
+// one of them publishes this rank's slot).
 __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, const PeerArgs &P,
-                                                     unsigned long long seq_given = 0ull, bool write_counter = true) {
+                                                     unsigned long long seq_given = 0ull, bool write_counter = true,
+                                                     bool publish = true) {
   __shared__ double s_pv[2][ABFT_PEER_MAX_RANKS];
   __shared__ double s_mine[2];
   __shared__ unsigned long long s_pseq;
@@ -276,7 +279,7 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
   const uint32_t t = threadIdx.x;
   if (t == 0) {
     const unsigned long long seq = seq_given ? seq_given : *P.counter + 1ull;  // (counter: written by the previous all-reduce on this stream)
-    if (!P.boards) {
+    if (!P.boards && publish) {
       PeerSlot *mine = P.board + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank;
       // two 16-byte stores, {v0, v1} and {sequence number, check word}, not waited for and in no
       // particular order: a reader takes a slot only when its check word fits the sequence number AND
@@ -299,7 +302,7 @@ __device__ __forceinline__ void peer_allreduce_block(double &v0, double &v1, con
   // rank polls only its OWN copy, in its own memory.  Same slot format, same check word.
   const PeerSlot *poll = P.board;
   if (P.boards) {
-    if (t < (uint32_t)P.size) {
+    if (publish && t < (uint32_t)P.size) {
       const double m0 = s_mine[0], m1 = s_mine[1];
       u64x2 *half = reinterpret_cast<u64x2 *>(P.boards[t] + (size_t)(seq & 1ull) * ABFT_PEER_MAX_RANKS + P.rank);
       sys_store_b128(half, u64x2{(unsigned long long)__double_as_longlong(m0), (unsigned long long)__double_as_longlong(m1)});
@@ -3045,6 +3048,13 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
   // the board's sequence number as the previous launch left it: this launch's all-reduces are seq0 + 1 and + 2
   const unsigned long long seq0 = a.f.peers.size ? *a.f.peers.counter : 0ull;
+  // A hand-off through memory costs a few microseconds (the L2s of the XCDs meet in memory), so wherever the input
+  // of a fold is small EVERY workgroup folds it for itself instead of waiting for one that does: the SpMV's partials
+  // (unless there are thousands of them, or the COO fix-up has to run first), the block partials of r.r, and -- with
+  // the board in device memory -- the ranks' slots, which every workgroup reads from this rank's own copy while
+  // workgroup 0 alone publishes.  Same folds, same order: same bits in every workgroup.
+  const bool each_a = !a.fx.on && !a.fold_nb && (a.f.peers.size == 0 || a.f.peers.boards != nullptr);
+  const bool each_b = a.o.peers.size == 0 || a.o.peers.boards != nullptr;
 
   // ---- A: p.w ----
   if (a.fx.on && blockIdx.x == 0) {
@@ -3080,7 +3090,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       __hip_atomic_fetch_add(a.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (blockIdx.x == 0) {
+  if (each_a || blockIdx.x == 0) {
     double tot = 0.0, evs = 0.0;
     if (a.fold_nb) {
       if (t == 0) {
@@ -3115,15 +3125,20 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     }
     if (t == 0) evs = (double)__hip_atomic_load(a.f.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (a.f.peers.size) peer_allreduce_block(tot, evs, a.f.peers, seq0 + 1ull, false);
+    if (a.f.peers.size) peer_allreduce_block(tot, evs, a.f.peers, seq0 + 1ull, false, blockIdx.x == 0);
     if (t == 0) {
-      __hip_atomic_store(a.f.dev_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.f.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0) {  // the pair itself: the caller's, and the next launch's rr / pw
+        __hip_atomic_store(a.f.dev_out, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.f.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!each_a) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      s_scal = tot;
     }
   }
-  if (t == 0) {
+  if (!each_a && t == 0) {
     const bool ok = tail_wait_ge(a.sync + 0, 1u, a.timeout_ticks);
     const double pw = __hip_atomic_load(a.f.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_scal = ok ? pw : nan;
@@ -3131,6 +3146,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   __syncthreads();
   const double rr = *a.rr;
   const double alpha = rr / s_scal;  // cg.cpp:102
+  __syncthreads();  // (s_scal is written again below)
 
   // ---- B: r -= alpha w; r.r  (calc_r_kernel on a grid of nbv blocks) ----
   const long stride = (long)a.nbv * ABFT_BLOCK * VEC;
@@ -3159,12 +3175,13 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   }
   if (t == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const uint32_t last = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
-    if (last) {
+    uint32_t fold = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+    if (each_b && !fold) fold = tail_wait_ge(a.sync + 1, gridDim.x, a.timeout_ticks) ? 1u : 2u;  // everybody folds (2: gave up)
+    if (fold) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    s_last = last;
+    s_last = fold;
   }
   __syncthreads();
   if (s_last) {  // (uniform in the workgroup)
@@ -3173,17 +3190,27 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       acc += __hip_atomic_load(a.o.partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     acc = quarter_sum(acc, s_w);
     double evs = 0.0;
-    if (t == 0) evs = (double)__hip_atomic_load(a.o.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a.o.peers.size) peer_allreduce_block(acc, evs, a.o.peers, seq0 + 2ull, true);
     if (t == 0) {
-      __hip_atomic_store(a.o.dev_out, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.o.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      evs = (double)__hip_atomic_load(a.o.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s_last == 2u) acc = nan;
+    }
+    // (each_b: workgroup 0 speaks for the rank; else the one workgroup that folds does)
+    const bool speaker = !each_b || blockIdx.x == 0;
+    if (a.o.peers.size) peer_allreduce_block(acc, evs, a.o.peers, seq0 + 2ull, speaker, speaker);
+    if (t == 0) {
+      if (speaker) {
+        __hip_atomic_store(a.o.dev_out, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.o.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!each_b) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      s_scal = acc;
     }
   }
   __syncthreads();
-  if (t == 0) {
+  if (!each_b && t == 0) {
     const bool ok = tail_wait_ge(a.sync + 2, 1u, a.timeout_ticks);
     const double rn = __hip_atomic_load(a.o.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_scal = ok ? rn : nan;

@@ -29,9 +29,11 @@ for tag in laplace_none laplace_sed laplace_secded random_secded powerlaw_coo_se
 done
 # the tail of the iteration in one launch (cg_tail_kernel) on configs[3]'s 1/8 shard size and the graph loop of config 2:
 # kernel traces of the C++ driver's --bench loop
-for spec in "random:524288,24,1 secded tail_shard" "random:4194304,24,1 secded tail_config4"; do
+for spec in "random:524288,24,1 secded tail_shard 1" "random:524288,24,1 secded three_kernels_shard 0" "random:4194304,24,1 secded tail_config4 1"; do
   set -- $spec
+  export ABFT_CG_TAIL=$4
   rocprofv3 --kernel-trace --stats -f csv -d $O/trace_$3 -- abft_sparse_cg_amd/host/cg-csr -t hip -m $2 -s $1 --bench 20,200,5 -q > $O/bench_under_trace_$3.txt 2> $O/trace_$3.err
   python3 profiles/summarize.py trace $O/trace_$3 $O/kernel_trace_$3.md > /dev/null
   rm -rf $O/trace_$3
 done
+unset ABFT_CG_TAIL
