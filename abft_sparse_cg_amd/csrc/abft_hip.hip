@@ -381,6 +381,37 @@ static void matrix_free(abft_hip_matrix *m) {
                 "LDS writes) %.1f, barrier %.1f, row sums %.1f, rest %.1f\n", 100.0 * t[0] / t[5], 100.0 * t[1] / t[5],
                 100.0 * t[2] / t[5], 100.0 * t[3] / t[5], 100.0 * t[4] / t[5],
                 100.0 * (t[5] - t[0] - t[1] - t[2] - t[3] - t[4]) / t[5]);
+      if (t[5] && m->sweep.debug_wg) {
+        // per workgroup (timing builds): the time a workgroup was NOT parked at the pacing check is what the others of
+        // its XCD wait for; its spread inside an XCD is the pacing wait
+        const uint32_t ng = std::min<uint32_t>(m->sweep_grid, m->sweep.ngroups);
+        std::vector<unsigned long long> w(4u * (size_t)ng);
+        if (hipMemcpy(w.data(), m->sweep.debug_wg, w.size() * sizeof(w[0]), hipMemcpyDeviceToHost) == hipSuccess) {
+          std::vector<double> busy, stage;
+          double by_xcd[8] = {0}, n_xcd[8] = {0}, mx_xcd[8] = {0};
+          for (uint32_t g = 0; g < ng; g++) {
+            if (!w[4u * g]) continue;
+            const double b = (double)(w[4u * g] - w[4u * g + 1]);
+            busy.push_back(b);
+            stage.push_back((double)w[4u * g + 2]);
+            const int x = (int)((w[4u * g + 3] >> 32) & 7u);
+            by_xcd[x] += b; n_xcd[x] += 1.0; mx_xcd[x] = std::max(mx_xcd[x], b);
+          }
+          if (!busy.empty()) {
+            std::sort(busy.begin(), busy.end());
+            std::sort(stage.begin(), stage.end());
+            const size_t n = busy.size();
+            fprintf(stderr, "sweep workgroups (%zu): clocks not at the pacing check, relative to the median: min %.3f p10 %.3f "
+                    "p90 %.3f max %.3f; staging alone: min %.3f p90 %.3f max %.3f\n", n, busy[0] / busy[n / 2],
+                    busy[n / 10] / busy[n / 2], busy[n * 9 / 10] / busy[n / 2], busy[n - 1] / busy[n / 2],
+                    stage[0] / stage[n / 2], stage[n * 9 / 10] / stage[n / 2], stage[n - 1] / stage[n / 2]);
+            fprintf(stderr, "  per XCD, slowest workgroup / mean workgroup:");
+            for (int x = 0; x < 8; x++)
+              if (n_xcd[x] > 0) fprintf(stderr, " %.3f", mx_xcd[x] / (by_xcd[x] / n_xcd[x]));
+            fprintf(stderr, "\n");
+          }
+        }
+      }
     }
   }
   if (m->use_panels && m->panels.debug) {
@@ -669,6 +700,11 @@ static int finish_sweep(abft_hip_matrix *m, const SweepBuild &sb, uint32_t capac
     if ((rc = dev_upload(m, &d_dbg, z, 16, 16))) return rc;
     HIPCHK(hipStreamSynchronize(m->ctx->stream));
     m->sweep.debug = d_dbg;
+    unsigned long long *d_wg = nullptr;
+    std::vector<unsigned long long> zw(4u * (size_t)std::max<uint32_t>(sb.ngroups, 1u), 0ull);
+    if ((rc = dev_upload(m, &d_wg, zw.data(), zw.size(), zw.size()))) return rc;
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+    m->sweep.debug_wg = d_wg;
   }
   return ABFT_OK;
 }

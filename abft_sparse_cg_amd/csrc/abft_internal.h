@@ -69,6 +69,7 @@ struct SweepLayout {
   uint32_t *pace;          // exit ticket, registrations per XCD, a progress board per XCD (kernels.hip: PACE_*)
   uint32_t lag;            // workgroups of an XCD stay within `lag` panels of its slowest; 0: no pacing
   uint32_t *debug;         // optional (ABFT_HIP_SWEEP_DEBUG): {polls that waited, waits, workgroup exits}, never reset
+  unsigned long long *debug_wg;  // optional, -DABFT_DBG_STAMPS builds: per workgroup {clocks in all, at the pacing check, staging, hardware id}
 };
 
 // Slice layout (round 3; opt-in, ABFT_HIP_LAYOUT=slice: built to test whether the sweep kernel's bookkeeping

@@ -2131,6 +2131,13 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
       STAMP(t_end);
       dbg_t[5] = t_end - t_begin;
       for (int k = 0; k < 6; k++) atomicAdd(reinterpret_cast<unsigned long long *>(L.debug + 4) + k, dbg_t[k]);
+      if (L.debug_wg) {  // per workgroup, summed over launches: where the SLOW workgroups of an XCD lose their time
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned long long *w = L.debug_wg + 4u * blockIdx.x;
+        w[0] += dbg_t[5]; w[1] += dbg_t[1]; w[2] += dbg_t[2];
+        w[3] = ((unsigned long long)xcc_id() << 32) | hw;
+      }
 #endif
     }
     // done: never holds anyone back, and the board is clean for the next launch

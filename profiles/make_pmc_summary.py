@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03/pmc_*.json (separate rocprofv3 --pmc passes, condensed by summarize.py)
+"""profiles/r04/pmc_*.json (ABFT_PROFILE_ROUND picks another round) (separate rocprofv3 --pmc passes, condensed by summarize.py)
 -> profiles/pmc_summary.json: HBM bytes per SpMV, which bench.py reports as
 roofline.traffic.
 
@@ -16,7 +16,7 @@ import json
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-R = os.path.join(HERE, "r03")
+R = os.path.join(HERE, os.environ.get("ABFT_PROFILE_ROUND", "r04"))
 CASES = {  # tag -> (workload key used by bench.py, bench line of the traced run)
     "laplace_none": ("laplace5:3162,3162/csr/none", "bench_under_trace_laplace_none.json"),
     "laplace_sed": ("laplace5:3162,3162/csr/sed", "bench_under_trace_laplace_sed.json"),
