@@ -46,7 +46,7 @@ Additional options of this build:
   -s  --synthetic       SPEC  Generate the matrix in memory instead of -f:
                               laplace5:NX,NY | random:N,K,SEED | powerlaw:N,SEED
       --seed            N     Seed for the -x draws (default: time)
-      --flip-at  I:B[,B...]   Flip the given bit(s) of matrix element I
+      --flip-at  I:B[,B...]   Flip the given bit(s) of matrix element I (may be repeated)
   -q  --quiet                 Do not print the per-iteration residual
 
 """
@@ -121,7 +121,7 @@ def parse(argv):
         elif a == "--flip-at":
             try:
                 idx, bits = arg("Invalid --flip-at (want INDEX:BIT[,BIT...])").split(":")
-                o["flip_at"] = (int(idx), [int(b) for b in bits.split(",")])
+                o["flip_at"] = (o["flip_at"] or []) + [(int(idx), [int(b) for b in bits.split(",")])]  # repeatable: one element each
             except ValueError:
                 fail("Invalid --flip-at (want INDEX:BIT[,BIT...])")
         elif a in ("--quiet", "-q"):
@@ -153,16 +153,16 @@ def bit_range(fmt, kind):
 
 
 def draw_flips(o, nnz):
-    """-> (index, [bits]) with the reference's rand() draw order, or None"""
+    """-> [(index, [bits]), ...]: --flip-at's elements in the order given, or one element drawn in the reference's rand() order"""
     if o["flip_at"] is not None:
         return o["flip_at"]
     if not o["flips"]:
-        return None
+        return []
     libc = ctypes.CDLL(None)
     libc.srand(o["seed"] if o["seed"] is not None else int(time.time()))
     index = libc.rand() % nnz
     lo, hi = bit_range(o["fmt"], o["kind"])
-    return index, [libc.rand() % (hi - lo) + lo for _ in range(o["flips"])]
+    return [(index, [libc.rand() % (hi - lo) + lo for _ in range(o["flips"])])]
 
 
 def main(argv=None):
@@ -217,11 +217,10 @@ def run_single(o):
     b, x, r, p, w = (ctx.create_vector(n) for _ in range(5))
     ctx.upload(b, generators.reference_rhs(n))
     ctx.upload(x, np.zeros(n))
-    flip = draw_flips(o, nnz)
-    if flip:
-        for bit in flip[1]:
-            print("*** flipping bit %d at index %d ***" % (bit, flip[0]))
-        ctx.inject_at(A, flip[0], flip[1])
+    for index, bits in draw_flips(o, nnz):
+        for bit in bits:
+            print("*** flipping bit %d at index %d ***" % (bit, index))
+        ctx.inject_at(A, index, bits)
     t0 = time.perf_counter()
     ctx.copy_vector(r, b)
     ctx.copy_vector(p, r)

@@ -1100,6 +1100,8 @@ static int create_any(abft_hip_ctx *ctx, int format, int mode, const uint32_t *c
       m->panel_chunk = 0;
       m->panel_grid = std::min<uint32_t>(m->panels.ngroups, std::max(resident, 1u));
     }
+    // (tests: fewer workgroups than groups, i.e. several rounds of groups per workgroup, on small matrices)
+    if (const char *e = getenv("ABFT_HIP_PANEL_GRID")) m->panel_grid = std::max<uint32_t>(1u, std::min<uint32_t>(m->panel_grid, (uint32_t)std::max(1L, atol(e))));
   }
   if (nblk > 0) {  // spmv can also deliver vec[x_off + row].result[row]
     // one partial per SpMV workgroup: row blocks (streaming) or output groups (panels)

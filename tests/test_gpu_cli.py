@@ -120,10 +120,12 @@ def test_replayed_flip_is_corrected_once(fmt, bit, msg):
     assert strip(hit.stdout) == strip(clean.stdout)
 
 
-def test_flip_at_may_be_repeated():
+@pytest.mark.parametrize("driver", ["cpp", "python"])
+def test_flip_at_may_be_repeated(driver):
     """--flip-at once per element: two elements repaired, each reported once, the solve equal to the clean one"""
-    clean = run("csr", ["-f", MTX, "-b", "1", "-m", "secded"])
-    hit = run("csr", ["-f", MTX, "-b", "1", "-m", "secded", "--flip-at", "1234:70", "--flip-at", "77:3"])
+    go = (lambda a: run("csr", a)) if driver == "cpp" else (lambda a: run_py(a))  # noqa: E731
+    clean = go(["-f", MTX, "-b", "1", "-m", "secded"])
+    hit = go(["-f", MTX, "-b", "1", "-m", "secded", "--flip-at", "1234:70", "--flip-at", "77:3"])
     assert clean.returncode == 0 and hit.returncode == 0
     assert hit.stdout.count("[ECC] corrected bit 70 at index 1234\n") == 1 and hit.stdout.count("[ECC] corrected bit 3 at index 77\n") == 1
     assert hit.stdout.index("index 77\n") < hit.stdout.index("[ECC] corrected bit 70")  # events print in index order

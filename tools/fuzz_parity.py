@@ -74,6 +74,15 @@ def one_case(seed):
     os.environ["ABFT_HIP_LAYOUT"] = layout
     os.environ["ABFT_HIP_PANEL_WIDTH"] = str(int(rng.choice([16, 100, 257, 4096])))
     os.environ["ABFT_HIP_PANEL_CHUNK"] = str(int(rng.choice([0, 1, 2, 3])))
+    # round 4, COO panel layout: all panels in one launch paced by the per-XCD board (lag > 0; overrides the chunking),
+    # workgroups that take several groups in turn, and the opt-in kernels (producer / consumer waves, cold paths out of
+    # the hot loop, the x prefetch)
+    os.environ["ABFT_HIP_PANEL_LAG"] = str(int(rng.choice([0, 0, 1, 2, 3])))
+    os.environ["ABFT_HIP_PANEL_GRID"] = str(int(rng.choice([1, 2, 3, 1000000])))
+    kern = int(rng.integers(0, 4))
+    os.environ["ABFT_HIP_COO_PC"] = "1" if kern == 1 else "0"
+    os.environ["ABFT_HIP_COO_LEAN"] = "1" if kern == 2 else "0"
+    os.environ["ABFT_HIP_PANEL_XPF"] = str(int(rng.integers(0, 2)))
     flips = []
     if nnz and (mode not in ("none", "constraints") or rng.random() < 0.7):
         for _ in range(int(rng.integers(0, 4))):

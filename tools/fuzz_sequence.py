@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from _oracle import CSR, OracleMatrix, laplace5, random_spd  # noqa: E402
 
 import abft_sparse_cg_amd as amd  # noqa: E402
+from abft_sparse_cg_amd import capi  # noqa: E402
 
 
 def bits_equal(a, b):
@@ -38,12 +39,13 @@ def one_case(seed):
     try:
         A = ctx.create_matrix(cols, rows, vals, n, len(vals))
         dev = [ctx.create_vector(n) for _ in range(NV)]
+        sc = ctx.create_vector(6)  # device scalars of "devstep": {rr, -}, {rr_new, events}, {p.w, events}
         model = [rng.standard_normal(n) for _ in range(NV)]
         for d, m in zip(dev, model):
             ctx.upload(d, m)
         trace = []
         for step in range(int(rng.integers(10, 60))):
-            op = str(rng.choice(["spmv", "dot", "calc_xr", "calc_p", "copy", "download", "upload", "cgstep"]))
+            op = str(rng.choice(["spmv", "dot", "calc_xr", "calc_p", "copy", "download", "upload", "cgstep", "devstep"]))
             ids = [int(i) for i in rng.permutation(NV)]
             trace.append((op, ids[:4]))
             if op == "spmv":
@@ -76,6 +78,29 @@ def one_case(seed):
                 if op == "cgstep":
                     beta = float(rng.uniform(-0.5, 0.5))
                     ctx.calc_p(dev[p], dev[r], beta)
+                    model[p] = model[r] + beta * model[p]
+            elif op == "devstep":
+                # round 4: the whole iteration with the scalars on the device (abft_hip_cg_iteration_dev: SpMV + ONE launch
+                # for the fold, the r half and the x / p half); alpha and beta are IEEE quotients of what it leaves behind
+                x, r, p, w = ids[:4]
+                cur = float(rng.uniform(0.5, 2.0))
+                ctx.upload(sc, np.array([cur, 0.0, 0.0, 0.0, 0.0, 0.0]))
+                base = sc.device_ptr
+                capi.check(ctx.L.abft_hip_cg_iteration_dev(ctx.h, A.h, dev[p].h, 0, capi.PART_ALL, dev[x].h, dev[r].h, dev[p].h,
+                                                           dev[w].h, base, base + 32, base + 16))
+                got = ctx.download(sc)
+                model[w] = o.spmv(model[p])
+                want_pw = float(np.dot(model[p], model[w]))
+                if not abs(got[4] - want_pw) <= 1e-12 * float(np.abs(model[p] * model[w]).sum()) + 1e-300:
+                    return "seed %d step %d %s: devstep p.w %r vs %r" % (seed, step, trace[-6:], got[4], want_pw)
+                with np.errstate(all="ignore"):
+                    alpha = np.float64(cur) / np.float64(got[4])
+                    model[x] = model[x] + alpha * model[p]
+                    model[r] = model[r] - alpha * model[w]
+                    want_rr = float(np.dot(model[r], model[r]))
+                    if np.isfinite(want_rr) and not abs(got[2] - want_rr) <= 1e-12 * want_rr + 1e-300:
+                        return "seed %d step %d %s: devstep r.r %r vs %r" % (seed, step, trace[-6:], got[2], want_rr)
+                    beta = np.float64(got[2]) / np.float64(cur)
                     model[p] = model[r] + beta * model[p]
             elif op == "calc_p":
                 p, r = ids[:2]
