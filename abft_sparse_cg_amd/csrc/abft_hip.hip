@@ -52,9 +52,9 @@ struct abft_hip_ctx {
   hipStream_t own_stream = nullptr, stream = nullptr;
   double *partials = nullptr;  // ABFT_MAX_PARTIALS doubles
   uint32_t *ticket = nullptr;  // reduction arrival counter (device)
-  uint32_t *tail_sync = nullptr;  // cg_tail_kernel's hand-off words (device, zero between launches)
+  unsigned long long *tail_sync = nullptr;  // cg_tail_kernel's hand-off words (device; they only ever grow)
   bool tail_enabled = true;       // ABFT_HIP_TAIL=0: the iteration's tail as its three kernels
-  int tail_cap[2] = {-1, -1};     // workgroups of cg_tail_kernel<1> / <2> that are resident at once (asked once)
+  int tail_cap[3] = {-1, -1, -1}; // workgroups of cg_tail_kernel<1> / <2> / <2, fast> that are resident at once (asked once)
   int sharers = 1;                // processes that run this library on this device at the same time (abft_hip_set_sharers)
   uint32_t seq = 0;            // last sequence number handed to a reduction
   bool spin_wait = true;       // wait for scalars by polling the pinned slot
@@ -258,8 +258,8 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   HIPCHK(hipMalloc((void **)&ctx->partials, ABFT_MAX_PARTIALS * sizeof(double)));
   HIPCHK(hipMalloc((void **)&ctx->ticket, ABFT_TICKET_WORDS * sizeof(uint32_t)));
   HIPCHK(hipMemset(ctx->ticket, 0, ABFT_TICKET_WORDS * sizeof(uint32_t)));
-  HIPCHK(hipMalloc((void **)&ctx->tail_sync, 8 * sizeof(uint32_t)));
-  HIPCHK(hipMemset(ctx->tail_sync, 0, 8 * sizeof(uint32_t)));
+  HIPCHK(hipMalloc((void **)&ctx->tail_sync, 64 * sizeof(unsigned long long)));
+  HIPCHK(hipMemset(ctx->tail_sync, 0, 64 * sizeof(unsigned long long)));
   if (const char *e = getenv("ABFT_HIP_TAIL")) ctx->tail_enabled = strcmp(e, "0") != 0;
   if (const char *e = getenv("ABFT_HIP_SYNC")) ctx->spin_wait = strcmp(e, "stream") != 0;
   if (const char *e = getenv("ABFT_HIP_FUSE_DOT")) ctx->fuse_enabled = strcmp(e, "0") != 0;
@@ -306,6 +306,14 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipFree(ctx->partials);
   (void)hipFree(ctx->alpha_dev);
   (void)hipFree(ctx->ticket);
+  if (getenv("ABFT_HIP_TAIL_DEBUG") && ctx->tail_sync) {  // -DABFT_DBG_STAMPS builds: workgroup 0's wall clock (10 ns) at the phase boundaries of the last launch
+    unsigned long long w[64] = {0};
+    if (hipMemcpy(w, ctx->tail_sync, sizeof(w), hipMemcpyDeviceToHost) == hipSuccess && w[40])
+      fprintf(stderr, "cg_tail phases of the last launch (us, workgroup 0): loads issued %.2f, p.w known %.2f, r stored + partial out %.2f, "
+              "arrived %.2f, all arrived %.2f, r.r known %.2f, stores issued %.2f\n", 0.01 * (double)(w[41] - w[40]),
+              0.01 * (double)(w[42] - w[40]), 0.01 * (double)(w[43] - w[40]), 0.01 * (double)(w[44] - w[40]),
+              0.01 * (double)(w[45] - w[40]), 0.01 * (double)(w[46] - w[40]), 0.01 * (double)(w[47] - w[40]));
+  }
   (void)hipFree(ctx->tail_sync);
   (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
@@ -2266,14 +2274,20 @@ extern "C" int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat
                 disjoint(x, r) && disjoint(x, p) && disjoint(x, w) && disjoint(r, p) && disjoint(r, w) && disjoint(p, w);
   uint32_t grid = 0;
   const uint32_t nbv = (uint32_t)reduce_blocks(n);
+  bool fast = false;
   if (merged) {
-    int &cap = ctx->tail_cap[vec2 ? 1 : 0];
-    if (cap < 0) cap = cg_tail_blocks_per_cu(vec2) * ctx->num_cus;
-    // the workgroups wait for each other (and, across ranks, for the peers' launches): ALL of them must be resident.
-    // Several processes on one device (tests: ranks sharing the one GPU) each get their share of it, less a half
-    // for whatever else those processes have in flight.
-    const int mine = ctx->sharers > 1 ? cap / (2 * ctx->sharers) : cap;
-    grid = std::min<uint32_t>((nbv + 3u) / 4u, (uint32_t)std::max(mine, 0));
+    auto cap_of = [&](int which) {
+      int &cap = ctx->tail_cap[which];
+      if (cap < 0) cap = cg_tail_blocks_per_cu(which >= 1, which == 2) * ctx->num_cus;
+      // the workgroups wait for each other (and, across ranks, for the peers' launches): ALL of them must be resident.
+      // Several processes on one device (tests: ranks sharing the one GPU) each get their share of it, less a half
+      // for whatever else those processes have in flight.
+      return ctx->sharers > 1 ? cap / (2 * ctx->sharers) : cap;
+    };
+    // the register-resident form: every workgroup exactly four virtual blocks, a thread's chain at most four pairs
+    const uint32_t want = (nbv + 3u) / 4u;
+    fast = vec2 && !hold.fix.on && (long long)n <= (long long)nbv * 2048 && (int)want <= cap_of(2);  // (the COO fix-up rewrites entries of w: no early loads)
+    grid = fast ? want : std::min<uint32_t>(want, (uint32_t)std::max(cap_of(vec2 ? 1 : 0), 0));
     merged = grid > 0;
   }
   if (!merged) {
@@ -2306,7 +2320,7 @@ extern "C" int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat
   a.sync = ctx->tail_sync;
   a.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
   KernelTimer t(ctx, ABFT_K_CALC_XR);
-  HIPCHK(launch_cg_tail(a, vec2, grid, ctx->stream));
+  HIPCHK(launch_cg_tail(a, vec2, fast, grid, ctx->stream));
   return ABFT_OK;
 }
 

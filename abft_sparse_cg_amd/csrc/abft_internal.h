@@ -159,6 +159,12 @@ struct CooDev {
 #ifndef ABFT_CFG_COO_PANEL_EPT
 #define ABFT_CFG_COO_PANEL_EPT 4  // 16-byte elements per thread per tile of the COO panel kernel
 #endif
+#ifndef ABFT_CFG_DEAD_NT
+#define ABFT_CFG_DEAD_NT 0  // non-temporal loads of values read for the last time this iteration: bit 0 w in calc_r, 1 r in calc_px, 2 p in calc_px
+#endif
+#ifndef ABFT_CFG_X_NT
+#define ABFT_CFG_X_NT 0  // calc_px: x (touched once per iteration) by non-temporal loads and stores
+#endif
 #ifndef ABFT_CFG_COO_LEAN_WAVES
 #define ABFT_CFG_COO_LEAN_WAVES 8  // register budget of spmv_coo_lean_kernel, in waves per SIMD (8: 64 VGPRs)
 #endif
@@ -339,7 +345,7 @@ struct TailArgs {
   const double *w;
   int n;
   uint32_t nbv;         // reduce_blocks(n): the grid calc_r_kernel / calc_px_kernel would run on
-  uint32_t *sync;       // 5 words, zero between launches: flag A, arrivals B, flag B, exits, arrivals of the chunk fold
+  unsigned long long *sync;  // 32 words that never go back: counters, flags and the bases a launch leaves for the next (kernels.hip)
   unsigned long long timeout_ticks;  // wall_clock64 ticks (100 MHz) a workgroup waits at a hand-off at most
 };
 int spmv_coo_panels_blocks_per_cu(int mode);
@@ -349,8 +355,8 @@ hipError_t launch_spmv_coo_lean(int mode, const CooDev &A, const CsrPanels &P, c
                                 const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
 hipError_t launch_spmv_coo_pc(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
                               const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
-int cg_tail_blocks_per_cu(bool vec2);
-hipError_t launch_cg_tail(const TailArgs &a, bool vec2, uint32_t grid, hipStream_t s);
+int cg_tail_blocks_per_cu(bool vec2, bool fast);
+hipError_t launch_cg_tail(const TailArgs &a, bool vec2, bool fast, uint32_t grid, hipStream_t s);
 
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);

@@ -2922,7 +2922,13 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(double *__restrict__
   for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
     if (VEC == 2 && i + 1 < n) {
       double2 rv = *reinterpret_cast<double2 *>(r + i);
+#if ABFT_CFG_DEAD_NT & 1  // w is dead after this read (the next SpMV rewrites it)
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      const v2d wl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(w + i));
+      const double2 wv = make_double2(wl.x, wl.y);
+#else
       const double2 wv = *reinterpret_cast<const double2 *>(w + i);
+#endif
       rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
       *reinterpret_cast<double2 *>(r + i) = rv;
       acc += rv.x * rv.x;
@@ -2947,13 +2953,35 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(double *__restrict_
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
   for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
     if (VEC == 2 && i + 1 < n) {
+#if ABFT_CFG_X_NT || (ABFT_CFG_DEAD_NT & 6)
+      typedef double v2d __attribute__((ext_vector_type(2)));
+#endif
+#if ABFT_CFG_DEAD_NT & 4  // the old p is dead after this read
+      const v2d pl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p + i));
+      double2 pv = make_double2(pl.x, pl.y);
+#else
       double2 pv = *reinterpret_cast<double2 *>(p + i);
+#endif
+#if ABFT_CFG_X_NT  // x is touched once per iteration: keep it out of the caches (Infinity Cache included) that p, r, w could live in
+      const v2d xl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(x + i));
+      double2 xv = make_double2(xl.x, xl.y);
+#else
       double2 xv = *reinterpret_cast<double2 *>(x + i);
+#endif
+#if ABFT_CFG_DEAD_NT & 2  // r is not read again before the next iteration's calc_r rewrites it
+      const v2d rl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(r + i));
+      const double2 rv = make_double2(rl.x, rl.y);
+#else
       const double2 rv = *reinterpret_cast<const double2 *>(r + i);
+#endif
       xv.x += alpha * pv.x; xv.y += alpha * pv.y;  // calc_xr's x half, with p as calc_xr saw it
       pv.x = rv.x + beta * pv.x;
       pv.y = rv.y + beta * pv.y;
+#if ABFT_CFG_X_NT
+      __builtin_nontemporal_store(v2d{xv.x, xv.y}, reinterpret_cast<v2d *>(x + i));
+#else
       *reinterpret_cast<double2 *>(x + i) = xv;
+#endif
       *reinterpret_cast<double2 *>(p + i) = pv;
     } else {
       const double pv = p[i];
@@ -3037,7 +3065,14 @@ __device__ __forceinline__ double quarter_sum(double v, double *s_w) {  // block
   return (s_w[q4] + s_w[q4 + 1u]) + (s_w[q4 + 2u] + s_w[q4 + 3u]);
 }
 
-__device__ __forceinline__ bool tail_wait_ge(const uint32_t *word, uint32_t want, unsigned long long ticks) {
+// The hand-off words of cg_tail_kernel never go back: every launch reads, from `base`, the values the previous launch
+// left its counters and flags at, and waits for them to have GROWN by its own amounts (nothing to reset at the end,
+// no exit counter); workgroup 0 leaves the next launch's bases.  Layout of TailArgs::sync (64-bit words):
+//   [0..7]   arrivals of phase B, sharded by blockIdx & 7 (an atomic on one address retires one add per ~12 ns)
+//   [8]      arrivals of the chunk fold        [9] flag A (generation)        [10] flag B (generation)
+//   [12]     arrivals of phase B in one counter (host-memory board: ONE workgroup folds, the last to arrive)
+//   [16..23] base of [0..7] for this launch    [24] base of [8]    [25] generation of the previous launch    [27] base of [12]
+__device__ __forceinline__ bool tail_wait_ge64(const unsigned long long *word, unsigned long long want, unsigned long long ticks) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
   while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
     if ((unsigned long long)wall_clock64() - t0 > ticks) return false;
@@ -3046,13 +3081,45 @@ __device__ __forceinline__ bool tail_wait_ge(const uint32_t *word, uint32_t want
   return true;
 }
 
-template <int VEC>
+// all eight shards of the phase-B arrival counter have reached this launch's targets (the shards share one 64-byte
+// line); `want`: read from the bases BEFORE this workgroup's own arrival -- workgroup 0 rewrites the bases at its end
+__device__ __forceinline__ bool tail_wait_arrivals(const unsigned long long *sync, const unsigned long long *want,
+                                                   unsigned long long ticks) {
+  const unsigned long long t0 = (unsigned long long)wall_clock64();
+  for (;;) {
+    // (the eight words in four 16-byte loads that are in flight together: one trip to memory per look, not eight)
+    u64x2 c0, c1, c2, c3;
+    sys_load4_b128(reinterpret_cast<const u64x2 *>(sync), reinterpret_cast<const u64x2 *>(sync + 2),
+                   reinterpret_cast<const u64x2 *>(sync + 4), reinterpret_cast<const u64x2 *>(sync + 6), c0, c1, c2, c3);
+    if (c0.x >= want[0] && c0.y >= want[1] && c1.x >= want[2] && c1.y >= want[3] && c2.x >= want[4] && c2.y >= want[5] &&
+        c3.x >= want[6] && c3.y >= want[7])
+      return true;
+    if ((unsigned long long)wall_clock64() - t0 > ticks) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+// FAST (host: every workgroup owns exactly four virtual blocks and a thread's chain is at most four pairs, i.e. n <= 2^22
+// and nothing is looped over): the elements stay in registers from phase B to phase C, and the loads of a phase are
+// issued BEFORE the hand-off in front of it -- r and w before p.w is known, p and x before r.r is.
+#ifdef ABFT_DBG_STAMPS
+#define TSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) a.sync[40 + (k)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define TSTAMP(k)
+#endif
+template <int VEC, bool FAST>
 __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   __shared__ double s_w[16];
   __shared__ double s_scal;
   __shared__ uint32_t s_last;
   const uint32_t t = threadIdx.x, q = t >> 8, tq = t & 255u;
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  unsigned long long *sync = a.sync;
+  TSTAMP(0);
+  // (these scalars are only needed later: their loads run beside everything up to there instead of in front of it)
+  const double rr = *a.rr;
+  const uint32_t nev_a = __hip_atomic_load(a.f.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long gen = sync[25] + 1ull;  // (plain loads of what the previous launch left: visible at a kernel boundary)
   // the board's sequence number as the previous launch left it: this launch's all-reduces are seq0 + 1 and + 2
   const unsigned long long seq0 = a.f.peers.size ? *a.f.peers.counter : 0ull;
   // A hand-off through memory costs a few microseconds (the L2s of the XCDs meet in memory), so wherever the input
@@ -3062,7 +3129,29 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   // workgroup 0 alone publishes.  Same folds, same order: same bits in every workgroup.
   const bool each_a = !a.fx.on && !a.fold_nb && (a.f.peers.size == 0 || a.f.peers.boards != nullptr);
   const bool each_b = a.o.peers.size == 0 || a.o.peers.boards != nullptr;
+  const long stride = (long)a.nbv * ABFT_BLOCK * VEC;
 
+  // FAST: this thread's (at most four) pairs of r and w, on their way while p.w is being folded
+  constexpr int NK = FAST ? 4 : 1;
+  double2 rv[NK], wv[NK], pv[NK], xv[NK];
+  const uint32_t myvb = blockIdx.x * 4u + q;
+  const long i0 = ((long)myvb * ABFT_BLOCK + tq) * 2;
+  if (FAST) {
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      const long i = i0 + (long)k * stride;
+      rv[k] = wv[k] = make_double2(0.0, 0.0);
+      if (myvb < a.nbv && i + 1 < a.n) {
+        rv[k] = *reinterpret_cast<const double2 *>(a.r + i);
+        wv[k] = *reinterpret_cast<const double2 *>(a.w + i);
+      } else if (myvb < a.nbv && i < a.n) {  // the vector's odd last element
+        rv[k].x = a.r[i];
+        wv[k].x = a.w[i];
+      }
+    }
+  }
+
+  TSTAMP(1);
   // ---- A: p.w ----
   if (a.fx.on && blockIdx.x == 0) {
     // COO: moved products first (the fix-up corrects partial 0 and rewrites the receiving outputs of w, which the
@@ -3094,7 +3183,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     }
     if (blockIdx.x * 4u < a.fold_nb && t == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_fetch_add(a.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(sync + 8, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if (each_a || blockIdx.x == 0) {
@@ -3102,7 +3191,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     if (a.fold_nb) {
       if (t == 0) {
         const uint32_t senders = min(gridDim.x, (a.fold_nb + 3u) / 4u);
-        s_last = tail_wait_ge(a.sync + 4, senders, a.timeout_ticks) ? 1u : 0u;
+        s_last = tail_wait_ge64(sync + 8, sync[24] + senders, a.timeout_ticks) ? 1u : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
@@ -3130,7 +3219,9 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       if (t == 0)
         for (int k = 0; k < 16; k++) tot += s_w[k];
     }
-    if (t == 0) evs = (double)__hip_atomic_load(a.f.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (events queued up to the launch's start: the SpMV's -- nothing in this kernel queues any before this point,
+    // the COO fix-up aside, whose hand-off form reads the counter behind it)
+    if (t == 0) evs = a.fx.on ? (double)__hip_atomic_load(a.f.ev_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (double)nev_a;
     __syncthreads();
     if (a.f.peers.size) peer_allreduce_block(tot, evs, a.f.peers, seq0 + 1ull, false, blockIdx.x == 0);
     if (t == 0) {
@@ -3139,51 +3230,99 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
         __hip_atomic_store(a.f.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!each_a) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(a.sync + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sync + 9, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       s_scal = tot;
     }
   }
   if (!each_a && t == 0) {
-    const bool ok = tail_wait_ge(a.sync + 0, 1u, a.timeout_ticks);
+    const bool ok = tail_wait_ge64(sync + 9, gen, a.timeout_ticks);
     const double pw = __hip_atomic_load(a.f.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_scal = ok ? pw : nan;
   }
   __syncthreads();
-  const double rr = *a.rr;
   const double alpha = rr / s_scal;  // cg.cpp:102
   __syncthreads();  // (s_scal is written again below)
+  TSTAMP(2);
 
   // ---- B: r -= alpha w; r.r  (calc_r_kernel on a grid of nbv blocks) ----
-  const long stride = (long)a.nbv * ABFT_BLOCK * VEC;
-  for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
-    const uint32_t vb = base + q;
+  if (FAST) {
     double acc = 0.0;
-    if (vb < a.nbv) {
-      for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
-        if (VEC == 2 && i + 1 < a.n) {
-          double2 rv = *reinterpret_cast<double2 *>(a.r + i);
-          const double2 wv = *reinterpret_cast<const double2 *>(a.w + i);
-          rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
-          *reinterpret_cast<double2 *>(a.r + i) = rv;
-          acc += rv.x * rv.x;
-          acc += rv.y * rv.y;
-        } else {
-          const double rs = a.r[i] - alpha * a.w[i];
-          a.r[i] = rs;
-          acc += rs * rs;
-        }
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      const long i = i0 + (long)k * stride;
+      if (myvb < a.nbv && i + 1 < a.n) {
+        rv[k].x -= alpha * wv[k].x; rv[k].y -= alpha * wv[k].y;
+        *reinterpret_cast<double2 *>(a.r + i) = rv[k];
+        acc += rv[k].x * rv[k].x;
+        acc += rv[k].y * rv[k].y;
+      } else if (myvb < a.nbv && i < a.n) {
+        rv[k].x = rv[k].x - alpha * wv[k].x;
+        a.r[i] = rv[k].x;
+        acc += rv[k].x * rv[k].x;
       }
     }
     acc = quarter_sum(acc, s_w);
-    if (vb < a.nbv && tq == 0) __hip_atomic_store(a.o.partials + vb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (myvb < a.nbv && tq == 0) __hip_atomic_store(a.o.partials + myvb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+  } else {
+    for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
+      const uint32_t vb = base + q;
+      double acc = 0.0;
+      if (vb < a.nbv) {
+        for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
+          if (VEC == 2 && i + 1 < a.n) {
+            double2 r2 = *reinterpret_cast<double2 *>(a.r + i);
+            const double2 w2 = *reinterpret_cast<const double2 *>(a.w + i);
+            r2.x -= alpha * w2.x; r2.y -= alpha * w2.y;
+            *reinterpret_cast<double2 *>(a.r + i) = r2;
+            acc += r2.x * r2.x;
+            acc += r2.y * r2.y;
+          } else {
+            const double rs = a.r[i] - alpha * a.w[i];
+            a.r[i] = rs;
+            acc += rs * rs;
+          }
+        }
+      }
+      acc = quarter_sum(acc, s_w);
+      if (vb < a.nbv && tq == 0) __hip_atomic_store(a.o.partials + vb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
   }
+  if (FAST) {  // phase C's operands, on their way while r.r is being gathered
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      const long i = i0 + (long)k * stride;
+      pv[k] = xv[k] = make_double2(0.0, 0.0);
+      if (myvb < a.nbv && i + 1 < a.n) {
+        pv[k] = *reinterpret_cast<const double2 *>(a.p + i);
+        xv[k] = *reinterpret_cast<const double2 *>(a.x + i);
+      } else if (myvb < a.nbv && i < a.n) {
+        pv[k].x = a.p[i];
+        xv[k].x = a.x[i];
+      }
+    }
+  }
+  TSTAMP(3);
   if (t == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    uint32_t fold = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
-    if (each_b && !fold) fold = tail_wait_ge(a.sync + 1, gridDim.x, a.timeout_ticks) ? 1u : 2u;  // everybody folds (2: gave up)
+    uint32_t fold = 0u;
+    if (each_b) {
+      unsigned long long want[8];
+#pragma unroll
+      for (uint32_t k = 0; k < 8u; k++) want[k] = sync[16u + k] + (gridDim.x + 7u - k) / 8u;  // workgroups with blockIdx & 7 == k
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this thread's partial has left; the bases are read)
+      (void)__hip_atomic_fetch_add(sync + (blockIdx.x & 7u), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      TSTAMP(4);
+      fold = tail_wait_arrivals(sync, want, a.timeout_ticks) ? 1u : 2u;  // everybody folds (2: gave up)
+      TSTAMP(5);
+    } else {
+      // one workgroup folds and publishes (the board lives in host memory: one reader): the last to arrive at ONE counter
+      const unsigned long long last = sync[27] + gridDim.x - 1u;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      fold = __hip_atomic_fetch_add(sync + 12, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == last ? 1u : 0u;
+    }
     if (fold) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3210,7 +3349,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
         __hip_atomic_store(a.o.dev_out + 1, evs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!each_b) {
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(sync + 10, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
       s_scal = acc;
@@ -3218,50 +3357,79 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   }
   __syncthreads();
   if (!each_b && t == 0) {
-    const bool ok = tail_wait_ge(a.sync + 2, 1u, a.timeout_ticks);
+    const bool ok = tail_wait_ge64(sync + 10, gen, a.timeout_ticks);
     const double rn = __hip_atomic_load(a.o.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_scal = ok ? rn : nan;
   }
   __syncthreads();
   const double beta = s_scal / rr;  // cg.cpp:109
+  TSTAMP(6);
 
   // ---- C: x += alpha p; p = r + beta p  (calc_px_kernel on the same grid) ----
-  for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
-    const uint32_t vb = base + q;
-    if (vb >= a.nbv) continue;
-    for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
-      if (VEC == 2 && i + 1 < a.n) {
-        double2 pv = *reinterpret_cast<double2 *>(a.p + i);
-        double2 xv = *reinterpret_cast<double2 *>(a.x + i);
-        const double2 rv = *reinterpret_cast<const double2 *>(a.r + i);
-        xv.x += alpha * pv.x; xv.y += alpha * pv.y;
-        pv.x = rv.x + beta * pv.x;
-        pv.y = rv.y + beta * pv.y;
-        *reinterpret_cast<double2 *>(a.x + i) = xv;
-        *reinterpret_cast<double2 *>(a.p + i) = pv;
-      } else {
-        const double pv = a.p[i];
-        a.x[i] = a.x[i] + alpha * pv;
-        a.p[i] = a.r[i] + beta * pv;
+  if (FAST) {
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+      const long i = i0 + (long)k * stride;
+      if (myvb < a.nbv && i + 1 < a.n) {
+        xv[k].x += alpha * pv[k].x; xv[k].y += alpha * pv[k].y;
+        pv[k].x = rv[k].x + beta * pv[k].x;
+        pv[k].y = rv[k].y + beta * pv[k].y;
+        *reinterpret_cast<double2 *>(a.x + i) = xv[k];
+        *reinterpret_cast<double2 *>(a.p + i) = pv[k];
+      } else if (myvb < a.nbv && i < a.n) {
+        a.x[i] = xv[k].x + alpha * pv[k].x;
+        a.p[i] = rv[k].x + beta * pv[k].x;
+      }
+    }
+  } else {
+    for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
+      const uint32_t vb = base + q;
+      if (vb >= a.nbv) continue;
+      for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
+        if (VEC == 2 && i + 1 < a.n) {
+          double2 p2 = *reinterpret_cast<double2 *>(a.p + i);
+          double2 x2 = *reinterpret_cast<double2 *>(a.x + i);
+          const double2 r2 = *reinterpret_cast<const double2 *>(a.r + i);
+          x2.x += alpha * p2.x; x2.y += alpha * p2.y;
+          p2.x = r2.x + beta * p2.x;
+          p2.y = r2.y + beta * p2.y;
+          *reinterpret_cast<double2 *>(a.x + i) = x2;
+          *reinterpret_cast<double2 *>(a.p + i) = p2;
+        } else {
+          const double p1 = a.p[i];
+          a.x[i] = a.x[i] + alpha * p1;
+          a.p[i] = a.r[i] + beta * p1;
+        }
       }
     }
   }
-  // the last workgroup out leaves the hand-off words as the next launch expects them
-  if (t == 0 && __hip_atomic_fetch_add(a.sync + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u)
-    for (int k = 0; k < 5; k++) __hip_atomic_store(a.sync + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  TSTAMP(7);
+  // workgroup 0 leaves the next launch's bases: what this launch's counters stand at once everybody has arrived
+  // (everybody HAS read this launch's bases: they are read before the arrival, and phase B is behind us)
+  if (blockIdx.x == 0 && t == 0) {
+    if (each_b)
+      for (uint32_t k = 0; k < 8u; k++) sync[16u + k] += (gridDim.x + 7u - k) / 8u;
+    else
+      sync[27] += gridDim.x;
+    if (a.fold_nb) sync[24] += min(gridDim.x, (a.fold_nb + 3u) / 4u);
+    sync[25] = gen;
+  }
 }
 
-int cg_tail_blocks_per_cu(bool vec2) {
+int cg_tail_blocks_per_cu(bool vec2, bool fast) {
   int n = 0;
-  const hipError_t e = vec2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2>, 1024, 0)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<1>, 1024, 0);
+  hipError_t e;
+  if (fast) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2, true>, 1024, 0);
+  else if (vec2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2, false>, 1024, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<1, false>, 1024, 0);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
 
-hipError_t launch_cg_tail(const TailArgs &a, bool vec2, uint32_t grid, hipStream_t s) {
-  if (vec2) hipLaunchKernelGGL(cg_tail_kernel<2>, dim3(grid), dim3(1024), 0, s, a);
-  else hipLaunchKernelGGL(cg_tail_kernel<1>, dim3(grid), dim3(1024), 0, s, a);
+hipError_t launch_cg_tail(const TailArgs &a, bool vec2, bool fast, uint32_t grid, hipStream_t s) {
+  if (fast) hipLaunchKernelGGL((cg_tail_kernel<2, true>), dim3(grid), dim3(1024), 0, s, a);
+  else if (vec2) hipLaunchKernelGGL((cg_tail_kernel<2, false>), dim3(grid), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL((cg_tail_kernel<1, false>), dim3(grid), dim3(1024), 0, s, a);
   return hipGetLastError();
 }
 
