@@ -85,6 +85,7 @@ SIGNATURES = {
     "abft_hip_calc_xr_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "abft_hip_calc_p_ratio_dev": (C.c_int, [vp, vp, vp, vp, vp]),
     "abft_hip_set_sharers": (C.c_int, [vp, C.c_int]),
+    "abft_hip_speculation_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "abft_hip_cg_iteration_dev": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "abft_hip_write_pair": (C.c_int, [vp, vp, C.c_double, C.c_double]),
     "abft_hip_peer_board_bytes": (C.c_size_t, []),

@@ -46,6 +46,8 @@ struct ProfSlot {
   long launches = 0;
 };
 
+static constexpr uint32_t ABFT_HOST_SLOTS = 4;  // result slots in the pinned ring
+
 struct abft_hip_ctx {
   int device = 0;
   int num_cus = 256;
@@ -53,13 +55,38 @@ struct abft_hip_ctx {
   double *partials = nullptr;  // ABFT_MAX_PARTIALS doubles
   uint32_t *ticket = nullptr;  // reduction arrival counter (device)
   unsigned long long *tail_sync = nullptr;  // cg_tail_kernel's hand-off words (device; they only ever grow)
+  bool capturing = false;         // between abft_hip_graph_begin and _end
   bool tail_enabled = true;       // ABFT_HIP_TAIL=0: the iteration's tail as its three kernels
   int tail_cap[3] = {-1, -1, -1}; // workgroups of cg_tail_kernel<1> / <2> / <2, fast> that are resident at once (asked once)
   int sharers = 1;                // processes that run this library on this device at the same time (abft_hip_set_sharers)
   uint32_t seq = 0;            // last sequence number handed to a reduction
   bool spin_wait = true;       // wait for scalars by polling the pinned slot
-  HostSlot *host_slot = nullptr;      // pinned, device-visible
+  // pinned, device-visible: a ring of result slots, slot seq % ABFT_HOST_SLOTS for the reduction numbered seq (two
+  // reductions can be in flight since round 4: the fold of p.w and the speculated r.r behind it)
+  HostSlot *host_slot = nullptr;
   HostSlot *host_slot_dev = nullptr;  // its device alias
+  // Speculation (cross-call fusion no. 3, round 4; the host-scalar loop of cg.cpp:97-112): once the library has
+  // seen one iteration -- spmv(A,p,w), [dot(p,w)], calc_xr(x,r,p,w,alpha), calc_p(p,r,beta) -- it enqueues, right
+  // behind the NEXT spmv(A,p,w) and its fold, the r half and the x / p half of that iteration with alpha = rr / p.w
+  // and beta = rr_new / rr formed on the device, writing into SHADOW buffers.  When the caller's calc_xr / calc_p
+  // then arrive with the same vectors and bit-identical alpha / beta (the same IEEE quotients of the scalars it was
+  // handed), the shadows are swapped in -- no kernel is launched, the GPU never waited for the host; anything else
+  // drops the shadows and runs the call as written.  Same bits either way.  ABFT_HIP_SPECULATE=0 turns it off.
+  struct {
+    bool enabled = true;
+    bool learned = false;                 // x, r, p, w below are the vectors of the last complete iteration
+    abft_hip_vector *x = nullptr, *r = nullptr, *p = nullptr, *w = nullptr;
+    bool have_rr = false;                 // scal[rr_at] holds the scalar last handed to the caller (r.r), whose value is rr_host
+    int rr_at = 0;
+    double rr_host = 0.0;
+    int stage = 0;                        // 0: nothing in flight; 1: both halves enqueued; 2: r committed, x / p pending
+    uint32_t seq_rr = 0;                  // sequence number of the speculated r.r
+    double rr_new_host = 0.0;
+    double *shadow[3] = {nullptr, nullptr, nullptr};  // r, p, x
+    int shadow_n = 0;
+    double *scal = nullptr;               // device doubles: [0], [1] r.r (alternating), [2] p.w (+ their event counts behind: 6 doubles)
+    long commits = 0, drops = 0;
+  } spec;
   EventRing ring{};                   // device memory
   MovedList moved{};                  // COO elements with a silently corrupted column (device memory)
   int *bits_dev = nullptr;            // scratch for inject (32 ints)
@@ -152,6 +179,7 @@ struct abft_hip_vector {
   double *host = nullptr;  // pinned staging for map/unmap
   abft_hip_vector *root = nullptr;  // the allocation a view looks into (itself for an owner)
   bool exposed = false;             // root only: the raw device pointer was handed out
+  int views = 0;                    // root only: live views into this allocation
 };
 
 static constexpr uint32_t EVENT_CAP = 1u << 16;
@@ -168,9 +196,33 @@ static int flush_deferred(abft_hip_ctx *ctx) {
 // Every entry point starts here.  Unless the caller is the calc_p that can absorb
 // it (keep_deferred), a pending x += alpha p is enqueued first, so no call ever
 // sees x or p in any state the unfused sequence would not have produced.
-static int bind(abft_hip_ctx *ctx, bool keep_deferred = false) {
+static bool same_bits(double a, double b) { return memcmp(&a, &b, sizeof(a)) == 0; }
+
+// an in-flight speculation is void: its shadow buffers are never looked at again (stage 2: the committed r stays, the
+// x half it owed is the pending deferred update, which the caller's path applies like any other -- and the residual the
+// caller holds is the speculated one)
+static void spec_drop(abft_hip_ctx *ctx) {
+  auto &S = ctx->spec;
+  if (S.stage) S.drops++;
+  if (S.stage == 2) {
+    S.rr_at = 1 - S.rr_at;
+    S.rr_host = S.rr_new_host;
+  }
+  S.stage = 0;
+}
+static void spec_forget(abft_hip_ctx *ctx) {
+  spec_drop(ctx);
+  ctx->spec.learned = false;
+  ctx->spec.have_rr = false;
+  ctx->spec.x = ctx->spec.r = ctx->spec.p = ctx->spec.w = nullptr;
+}
+
+// (keep_spec: the caller is one of the continuations a speculation waits for -- dot(p, w), calc_xr, calc_p -- and
+// decides itself; every other entry point voids it)
+static int bind(abft_hip_ctx *ctx, bool keep_deferred = false, bool keep_spec = false) {
   if (!ctx) return set_err(ABFT_ERR_INVALID, "null context");
   HIPCHK(hipSetDevice(ctx->device));
+  if (!keep_spec) spec_drop(ctx);
   if (!keep_deferred) return flush_deferred(ctx);
   return ABFT_OK;
 }
@@ -265,8 +317,11 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   if (const char *e = getenv("ABFT_HIP_FUSE_DOT")) ctx->fuse_enabled = strcmp(e, "0") != 0;
   if (const char *e = getenv("ABFT_HIP_FUSE_X")) ctx->defer_enabled = strcmp(e, "0") != 0;
   HIPCHK(hipMalloc((void **)&ctx->alpha_dev, sizeof(double)));
-  HIPCHK(hipHostMalloc((void **)&ctx->host_slot, sizeof(HostSlot), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(ctx->host_slot, 0, sizeof(HostSlot));
+  HIPCHK(hipHostMalloc((void **)&ctx->host_slot, ABFT_HOST_SLOTS * sizeof(HostSlot), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->host_slot, 0, ABFT_HOST_SLOTS * sizeof(HostSlot));
+  HIPCHK(hipMalloc((void **)&ctx->spec.scal, 8 * sizeof(double)));
+  HIPCHK(hipMemset(ctx->spec.scal, 0, 8 * sizeof(double)));
+  if (const char *e = getenv("ABFT_HIP_SPECULATE")) ctx->spec.enabled = strcmp(e, "0") != 0;
   HIPCHK(hipHostGetDevicePointer((void **)&ctx->host_slot_dev, ctx->host_slot, 0));
   HIPCHK(hipMalloc((void **)&ctx->ring.buf, EVENT_CAP * sizeof(abft_event)));
   HIPCHK(hipMalloc((void **)&ctx->ring.count, sizeof(uint32_t)));
@@ -315,6 +370,10 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
               0.01 * (double)(w[45] - w[40]), 0.01 * (double)(w[46] - w[40]), 0.01 * (double)(w[47] - w[40]));
   }
   (void)hipFree(ctx->tail_sync);
+  if (getenv("ABFT_HIP_VERBOSE") && (ctx->spec.commits || ctx->spec.drops))
+    fprintf(stderr, "hip: speculated iterations: %ld taken over, %ld dropped\n", ctx->spec.commits, ctx->spec.drops);
+  for (double *b : ctx->spec.shadow) (void)hipFree(b);
+  (void)hipFree(ctx->spec.scal);
   (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
   (void)hipFree(ctx->ring.count);
@@ -1328,6 +1387,7 @@ extern "C" int abft_hip_vector_view(abft_hip_vector *parent, int offset, int N, 
   if (!v) return set_err(ABFT_ERR_NOMEM, "vector allocation failed");
   v->ctx = parent->ctx; v->d = parent->d + offset; v->n = N; v->owns = false;
   v->root = parent->root ? parent->root : parent;
+  v->root->views++;
   *vec = v;
   return ABFT_OK;
 }
@@ -1336,7 +1396,9 @@ extern "C" int abft_hip_vector_destroy(abft_hip_vector *vec) {
   if (!vec) return ABFT_OK;
   if (int rc = bind(vec->ctx)) return rc;
   vec->ctx->fused.valid = false;
+  spec_forget(vec->ctx);  // (the learned iteration names vectors by handle)
   HIPCHK(hipStreamSynchronize(vec->ctx->stream));
+  if (!vec->owns && vec->root) vec->root->views--;
   if (vec->host) (void)hipHostFree(vec->host);
   if (vec->owns) (void)hipFree(vec->d);
   delete vec;
@@ -1375,7 +1437,7 @@ extern "C" int abft_hip_vector_copy(abft_hip_vector *dst, const abft_hip_vector 
 // library's back, so a pending update is applied now and none is deferred on it again.
 extern "C" void *abft_hip_vector_device_ptr(abft_hip_vector *vec) {
   if (!vec) return nullptr;
-  if (vec->ctx && vec->ctx->defer.active) (void)bind(vec->ctx);
+  if (vec->ctx) (void)bind(vec->ctx);  // (a pending x update is applied, a speculation dropped: the caller is about to look)
   (vec->root ? vec->root : vec)->exposed = true;
   return vec->d;
 }
@@ -1401,9 +1463,9 @@ static ReduceOut reduce_out(abft_hip_ctx *ctx, double *dev_out, bool to_host) {
   o.partials = ctx->partials;
   o.ticket = ctx->ticket;
   o.dev_out = dev_out;
-  o.host = to_host ? ctx->host_slot_dev : nullptr;
   o.ev_count = ctx->ring.count;
   o.seq = to_host ? ++ctx->seq : 0;
+  o.host = to_host ? ctx->host_slot_dev + (o.seq % ABFT_HOST_SLOTS) : nullptr;
   return o;
 }
 
@@ -1412,7 +1474,7 @@ static ReduceOut reduce_out(abft_hip_ctx *ctx, double *dev_out, bool to_host) {
 // once the value lands; hipStreamSynchronize costs tens.  The stream is queried
 // now and then so that a failed kernel ends the wait with an error instead of a hang.
 static int scalar_from_host_slot(abft_hip_ctx *ctx, uint32_t seq, double *result) {
-  HostSlot *slot = ctx->host_slot;
+  HostSlot *slot = ctx->host_slot + (seq % ABFT_HOST_SLOTS);
   if (!ctx->spin_wait) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
   } else {
@@ -1443,9 +1505,9 @@ static int check_same(const abft_hip_vector *a, const abft_hip_vector *b, const 
 }
 
 extern "C" int abft_hip_dot(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b, double *result) {
-  if (int rc = bind(ctx)) return rc;
-  if (int rc = check_same(a, b, "dot")) return rc;
-  if (!result) return set_err(ABFT_ERR_INVALID, "null result");
+  if (int rc = bind(ctx, false, true)) return rc;  // (a dot served from the fused product leaves a speculation alone)
+  if (int rc = check_same(a, b, "dot")) { spec_drop(ctx); return rc; }
+  if (!result) { spec_drop(ctx); return set_err(ABFT_ERR_INVALID, "null result"); }
   // dot(p, w) right after spmv(A, p, w): the SpMV already formed it
   if (ctx->fused.valid && a->n == ctx->fused.n &&
       ((a->d == ctx->fused.x && b->d == ctx->fused.y) || (a->d == ctx->fused.y && b->d == ctx->fused.x))) {
@@ -1456,13 +1518,19 @@ extern "C" int abft_hip_dot(abft_hip_ctx *ctx, const abft_hip_vector *a, const a
     *result = ctx->fused.value;
     return ABFT_OK;
   }
+  spec_drop(ctx);
   if (!ctx->fused.have_value) ctx->fused.valid = false;  // the slot is about to be reused
-  const ReduceOut o = reduce_out(ctx, nullptr, true);
+  // (the result also stays on the device: if this is the r.r a CG loop starts from, a speculated alpha divides it)
+  auto &S = ctx->spec;
+  const int at = S.have_rr ? 1 - S.rr_at : 0;
+  const ReduceOut o = reduce_out(ctx, S.scal + 2 * at, true);
   {
     KernelTimer t(ctx, ABFT_K_DOT);
     HIPCHK(launch_dot(a->d, b->d, a->n, o, ctx->stream));
   }
-  return scalar_from_host_slot(ctx, o.seq, result);
+  if (int rc = scalar_from_host_slot(ctx, o.seq, result)) { S.have_rr = false; return rc; }
+  S.have_rr = true; S.rr_at = at; S.rr_host = *result;
+  return ABFT_OK;
 }
 
 extern "C" int abft_hip_dot_dev(abft_hip_ctx *ctx, const abft_hip_vector *a, const abft_hip_vector *b, double *dev_result) {
@@ -1526,11 +1594,44 @@ static int calc_p_launch(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_v
 
 extern "C" int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r, const abft_hip_vector *p,
                                 const abft_hip_vector *w, double alpha, double *result) {
-  if (int rc = bind(ctx)) return rc;
-  if (!result) return set_err(ABFT_ERR_INVALID, "null result");
-  const ReduceOut o = reduce_out(ctx, nullptr, true);
-  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha, o)) return rc;
-  return scalar_from_host_slot(ctx, o.seq, result);
+  if (int rc = bind(ctx, false, true)) return rc;
+  if (!result) { spec_drop(ctx); return set_err(ABFT_ERR_INVALID, "null result"); }
+  auto &S = ctx->spec;
+  if (S.stage == 1) {
+    // the speculated r half is this very call if it names the same vectors and alpha is, bit for bit, the quotient of
+    // the two scalars the caller was (or could have been) handed: r.r and the fused p.w
+    bool take = x == S.x && r == S.r && p == S.p && w == S.w && ctx->fused.valid;
+    if (take && !ctx->fused.have_value) {
+      take = scalar_from_host_slot(ctx, ctx->fused.seq, &ctx->fused.value) == ABFT_OK;
+      ctx->fused.have_value = take;
+    }
+    take = take && same_bits(alpha, S.rr_host / ctx->fused.value);
+    if (take) {
+      double rr_new = 0.0;
+      if (int rc = scalar_from_host_slot(ctx, S.seq_rr, &rr_new)) { spec_drop(ctx); return rc; }
+      std::swap(r->d, S.shadow[0]);  // r is now what calc_r left in the shadow; its old buffer is the next shadow
+      ctx->fused.valid = false;
+      // x += alpha p is owed exactly as after a deferred calc_xr: the speculated x / p half holds it (stage 2), and
+      // if the caller does something else first, the pending update is applied in place like any other
+      ctx->defer.active = true; ctx->defer.on_dev = true;
+      ctx->defer.x = x->d; ctx->defer.p = p->d; ctx->defer.n = x->n; ctx->defer.alpha = alpha;
+      S.stage = 2;
+      S.rr_new_host = rr_new;
+      *result = rr_new;
+      return ABFT_OK;
+    }
+    spec_drop(ctx);
+  } else
+    spec_drop(ctx);
+  const int at = S.have_rr ? 1 - S.rr_at : 0;
+  const ReduceOut o = reduce_out(ctx, S.scal + 2 * at, true);
+  if (int rc = calc_xr_launch(ctx, x, r, p, w, alpha, o)) { S.have_rr = false; return rc; }
+  if (int rc = scalar_from_host_slot(ctx, o.seq, result)) { S.have_rr = false; return rc; }
+  // what a speculation would need to know about this iteration
+  S.have_rr = true; S.rr_at = at; S.rr_host = *result;
+  S.x = x; S.r = r; S.p = const_cast<abft_hip_vector *>(p); S.w = const_cast<abft_hip_vector *>(w);
+  S.learned = false;  // ... until the calc_p that completes it
+  return ABFT_OK;
 }
 
 extern "C" int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_vector *r,
@@ -1542,8 +1643,31 @@ extern "C" int abft_hip_calc_xr_dev(abft_hip_ctx *ctx, abft_hip_vector *x, abft_
 }
 
 extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft_hip_vector *r, double beta) {
-  if (int rc = bind(ctx, true)) return rc;
-  return calc_p_launch(ctx, p, r, beta, nullptr, nullptr);
+  if (int rc = bind(ctx, true, true)) return rc;
+  auto &S = ctx->spec;
+  if (S.stage == 2) {
+    // the speculated x / p half is this very call if it names p and r and beta is the quotient of the two residuals
+    const bool take = p == S.p && r == S.r && same_bits(beta, S.rr_new_host / S.rr_host) && ctx->defer.active &&
+                      ctx->defer.x == S.x->d && ctx->defer.p == p->d;
+    if (take) {
+      std::swap(p->d, S.shadow[1]);
+      std::swap(S.x->d, S.shadow[2]);
+      ctx->defer.active = false;
+      ctx->fused.valid = false;
+      S.stage = 0;
+      S.rr_at = 1 - S.rr_at;  // the speculated r.r is the residual the caller now holds
+      S.rr_host = S.rr_new_host;
+      S.commits++;
+      return ABFT_OK;
+    }
+    spec_drop(ctx);
+  } else
+    spec_drop(ctx);
+  // (learning: calc_p(p, r) right behind calc_xr(x, r, p, w) completes an iteration of the CG loop)
+  const bool completes = S.have_rr && !S.learned && S.p == p && S.r == r && S.x && S.w;
+  if (int rc = calc_p_launch(ctx, p, r, beta, nullptr, nullptr)) return rc;
+  S.learned = completes || (S.learned && S.p == p && S.r == r);
+  return ABFT_OK;
 }
 
 // {sum, events} that a collective left in device memory -> the host, through the pinned
@@ -1553,9 +1677,9 @@ extern "C" int abft_hip_read_pair(abft_hip_ctx *ctx, const double *dev_pair, dou
   if (!dev_pair || !value) return set_err(ABFT_ERR_INVALID, "null argument");
   if (!ctx->fused.have_value) ctx->fused.valid = false;  // the slot is about to be reused
   const uint32_t seq = ++ctx->seq;
-  HIPCHK(launch_publish_pair(dev_pair, ctx->host_slot_dev, seq, ctx->stream));
+  HIPCHK(launch_publish_pair(dev_pair, ctx->host_slot_dev + (seq % ABFT_HOST_SLOTS), seq, ctx->stream));
   if (int rc = scalar_from_host_slot(ctx, seq, value)) return rc;
-  if (events) *events = (double)ctx->host_slot->evcount;
+  if (events) *events = (double)ctx->host_slot[seq % ABFT_HOST_SLOTS].evcount;
   return ABFT_OK;
 }
 
@@ -2078,6 +2202,46 @@ extern "C" int abft_hip_calc_p_ratio_dev(abft_hip_ctx *ctx, abft_hip_vector *p, 
 
 // Shared by abft_hip_spmv (dev_pair == nullptr: the fused product, if any, goes to
 // the pinned slot for a following dot) and abft_hip_spmv_dot_dev.
+// ---- speculation (see abft_hip_ctx::spec) ----------------------------------------------------------
+static bool spec_plain(const abft_hip_vector *v, int n) {  // a whole allocation nobody else can see into
+  return v && v->owns && v->root == v && !v->exposed && v->views == 0 && v->n == n && v->d;
+}
+
+// behind spmv(A, p, w) + fold: the learned iteration's r half and x / p half into the shadow buffers
+static int spec_launch(abft_hip_ctx *ctx, const abft_hip_vector *vec, const abft_hip_vector *result) {
+  auto &S = ctx->spec;
+  if (!S.enabled || !S.learned || !S.have_rr || S.stage || ctx->defer.active || ctx->capturing) return ABFT_OK;
+  if (vec != S.p || result != S.w) return ABFT_OK;
+  const int n = vec->n;
+  if (n <= 0 || !spec_plain(S.x, n) || !spec_plain(S.r, n) || !spec_plain(S.p, n) || !spec_plain(S.w, n)) return ABFT_OK;
+  if (S.shadow_n != n) {
+    for (double *&b : S.shadow) { (void)hipFree(b); b = nullptr; }
+    S.shadow_n = 0;
+    for (double *&b : S.shadow)
+      if (hipMalloc((void **)&b, ((size_t)n + 2) * sizeof(double)) != hipSuccess) {  // no room: no speculation
+        (void)hipGetLastError();
+        for (double *&c : S.shadow) { (void)hipFree(c); c = nullptr; }
+        S.enabled = false;
+        return ABFT_OK;
+      }
+    S.shadow_n = n;
+  }
+  double *rr = S.scal + 2 * S.rr_at, *rr_new = S.scal + 2 * (1 - S.rr_at), *pw = S.scal + 4;
+  const ReduceOut o = reduce_out(ctx, rr_new, true);  // {r.r, events} to the host ring AND to the device
+  {
+    KernelTimer t(ctx, ABFT_K_CALC_XR);
+    HIPCHK(launch_calc_r(S.r->d, S.w->d, 0.0, rr, pw, ctx->alpha_dev, n, o, ctx->stream, S.shadow[0]));
+  }
+  {
+    KernelTimer t(ctx, ABFT_K_CALC_P);
+    HIPCHK(launch_calc_px(S.p->d, S.shadow[0], S.x->d, 0.0, rr_new, rr, 0.0, ctx->alpha_dev, n, ctx->stream, S.shadow[1],
+                          S.shadow[2]));
+  }
+  S.stage = 1;
+  S.seq_rr = o.seq;
+  return ABFT_OK;
+}
+
 // `hold` (abft_hip_cg_iteration_dev): the fold of the fused product is not launched; what it needs is left there
 struct HeldFold {
   bool held = false;
@@ -2129,10 +2293,10 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
   else if (part == ABFT_PART_BOUNDARY && n_int) span = TileSpan{0u, mat->t_lo, n_int, mat->csr.nblk - n_int};
   if (do_fuse) {
     fuse.partials = mat->fuse_partials;
-    fuse.host = dev_pair ? nullptr : ctx->host_slot_dev;
-    fuse.dev_out = dev_pair;
     fuse.ev_count = ctx->ring.count;
     fuse.seq = dev_pair ? 0 : ++ctx->seq;
+    fuse.host = dev_pair ? nullptr : ctx->host_slot_dev + (fuse.seq % ABFT_HOST_SLOTS);
+    fuse.dev_out = dev_pair ? dev_pair : ctx->spec.scal + 4;  // (host form: p.w stays on the device too, for a speculated alpha)
     fuse.x_off = dev_pair ? (uint32_t)vec_offset : 0u;
     if (dev_pair && ctx->peers.fuse) fuse.peers = peer_args(ctx);
   }
@@ -2198,6 +2362,7 @@ static int spmv_common(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_v
     ctx->fused.y = result->d;
     ctx->fused.n = vec->n;
     ctx->fused.seq = fuse.seq;
+    if (whole && part == ABFT_PART_ALL) (void)spec_launch(ctx, vec, result);
   }
   return ABFT_OK;
 }
@@ -2236,6 +2401,13 @@ extern "C" int abft_hip_spmv_dot_part_dev(abft_hip_ctx *ctx, abft_hip_matrix *ma
                                           abft_hip_vector *result, int vec_offset, double *dev_result, int part) {
   if (!dev_result) return set_err(ABFT_ERR_INVALID, "null result");
   return spmv_common(ctx, mat, vec, result, vec_offset, dev_result, part);
+}
+
+extern "C" int abft_hip_speculation_stats(abft_hip_ctx *ctx, long *taken, long *dropped) {
+  if (!ctx) return set_err(ABFT_ERR_INVALID, "null context");
+  if (taken) *taken = ctx->spec.commits;
+  if (dropped) *dropped = ctx->spec.drops;
+  return ABFT_OK;
 }
 
 extern "C" int abft_hip_set_sharers(abft_hip_ctx *ctx, int processes) {
@@ -2340,12 +2512,14 @@ extern "C" int abft_hip_graph_begin(abft_hip_ctx *ctx) {
   if (int rc = bind(ctx)) return rc;
   if (ctx->prof) return set_err(ABFT_ERR_INVALID, "graph capture with kernel brackets enabled (abft_hip_profile_enable)");
   HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+  ctx->capturing = true;
   return ABFT_OK;
 }
 
 extern "C" int abft_hip_graph_end(abft_hip_ctx *ctx, abft_hip_graph **out) {
   if (!ctx || !out) return set_err(ABFT_ERR_INVALID, "null argument");
   *out = nullptr;
+  ctx->capturing = false;
   if (ctx->defer.active) {  // the captured sequence must leave nothing pending on the host side
     hipGraph_t g = nullptr;
     (void)hipStreamEndCapture(ctx->stream, &g);
@@ -2419,7 +2593,16 @@ extern "C" int abft_format_event(const abft_event *ev, char *buf, size_t cap) {
   }
 }
 
-extern "C" int abft_hip_pending_events(abft_hip_ctx *ctx) { return ctx ? (int)ctx->host_slot->evcount : 0; }
+// (the count every published result carries: the largest over the ring is the latest)
+extern "C" int abft_hip_pending_events(abft_hip_ctx *ctx) {
+  uint32_t n = 0;
+  if (ctx)
+    for (uint32_t k = 0; k < ABFT_HOST_SLOTS; k++) n = std::max(n, ctx->host_slot[k].evcount);
+  return (int)n;
+}
+static void clear_pending_events(abft_hip_ctx *ctx) {
+  for (uint32_t k = 0; k < ABFT_HOST_SLOTS; k++) ctx->host_slot[k].evcount = 0;
+}
 
 extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap, int *count, int *fatal) {
   if (int rc = bind(ctx)) return rc;
@@ -2429,14 +2612,14 @@ extern "C" int abft_hip_drain_events(abft_hip_ctx *ctx, abft_event *buf, int cap
   uint32_t n = 0;
   HIPCHK(hipMemcpyAsync(&n, ctx->ring.count, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (n == 0) { ctx->host_slot->evcount = 0; return ABFT_OK; }
+  if (n == 0) { clear_pending_events(ctx); return ABFT_OK; }
   const uint32_t queued = n;
   if (n > ctx->ring.cap) n = ctx->ring.cap;  // push_event dropped the rest: reported below, never silently
   std::vector<abft_event> ev(n);
   HIPCHK(hipMemcpyAsync(ev.data(), ctx->ring.buf, (size_t)n * sizeof(abft_event), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->ring.count, 0, sizeof(uint32_t), ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->host_slot->evcount = 0;
+  clear_pending_events(ctx);
   // The order a single-threaded reference run meets them in.  ECC events and the COO
   // constraint checks: by element index.  The CSR constraint checks are made row by row --
   // a row's two row-pointer checks, then its elements in order (CSR/CPUContext.cpp:173-200) --

@@ -366,9 +366,10 @@ hipError_t launch_calc_xr(double *x, double *r, const double *p, const double *w
 hipError_t launch_calc_p(double *p, const double *r, double beta, const double *num, const double *den, int n,
                          hipStream_t s);
 hipError_t launch_calc_r(double *r, const double *w, double alpha, const double *num, const double *den,
-                         double *alpha_out, int n, const ReduceOut &out, hipStream_t s);
+                         double *alpha_out, int n, const ReduceOut &out, hipStream_t s, double *r_out = nullptr);
 hipError_t launch_calc_px(double *p, const double *r, double *x, double beta, const double *num, const double *den,
-                          double alpha, const double *alpha_ptr, int n, hipStream_t s);
+                          double alpha, const double *alpha_ptr, int n, hipStream_t s, double *p_out = nullptr,
+                          double *x_out = nullptr);
 hipError_t launch_axpy(double *x, const double *p, double alpha, const double *alpha_ptr, int n, hipStream_t s);
 hipError_t launch_publish_pair(const double *pair, HostSlot *host, uint32_t seq, hipStream_t s);
 

@@ -2910,10 +2910,11 @@ hipError_t launch_calc_p(double *p, const double *r, double beta, const double *
 // (calc_px_kernel: 40 N instead of 24 N) -- p is read once per iteration, 8 N bytes
 // less traffic, every x[i] and p[i] the same bits (same operands, same two roundings).
 
+// (r_out: where the updated r goes -- r itself, or the shadow buffer of a speculated iteration, abft_hip.hip "speculation")
 template <int VEC>
-__global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(double *__restrict__ r, const double *__restrict__ w,
+__global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(const double *r, const double *__restrict__ w,
                                                             double alpha, const double *num, const double *den,
-                                                            double *alpha_out, int n, ReduceOut out) {
+                                                            double *alpha_out, int n, ReduceOut out, double *r_out) {
   __shared__ double s_w[4];
   if (num) alpha = *num / *den;
   if (alpha_out && blockIdx.x == 0 && threadIdx.x == 0) *alpha_out = alpha;  // for the deferred x += alpha p
@@ -2921,7 +2922,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(double *__restrict__
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
   for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
     if (VEC == 2 && i + 1 < n) {
-      double2 rv = *reinterpret_cast<double2 *>(r + i);
+      double2 rv = *reinterpret_cast<const double2 *>(r + i);
 #if ABFT_CFG_DEAD_NT & 1  // w is dead after this read (the next SpMV rewrites it)
       typedef double v2d __attribute__((ext_vector_type(2)));
       const v2d wl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(w + i));
@@ -2930,12 +2931,12 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(double *__restrict__
       const double2 wv = *reinterpret_cast<const double2 *>(w + i);
 #endif
       rv.x -= alpha * wv.x; rv.y -= alpha * wv.y;
-      *reinterpret_cast<double2 *>(r + i) = rv;
+      *reinterpret_cast<double2 *>(r_out + i) = rv;
       acc += rv.x * rv.x;
       acc += rv.y * rv.y;
     } else {
       const double rs = r[i] - alpha * w[i];
-      r[i] = rs;
+      r_out[i] = rs;
       acc += rs * rs;
     }
   }
@@ -2943,11 +2944,12 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_r_kernel(double *__restrict__
   reduce_finish(acc, out, s_w);
 }
 
+// (p_out, x_out: where the new p and x go -- p and x themselves, or the shadow buffers of a speculated iteration)
 template <int VEC>
-__global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(double *__restrict__ p, const double *__restrict__ r,
-                                                             double *__restrict__ x, double beta,
+__global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(const double *p, const double *__restrict__ r,
+                                                             const double *x, double beta,
                                                              const double *num, const double *den, double alpha,
-                                                             const double *alpha_ptr, int n) {
+                                                             const double *alpha_ptr, int n, double *p_out, double *x_out) {
   if (num) beta = *num / *den;
   if (alpha_ptr) alpha = *alpha_ptr;
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
@@ -2960,13 +2962,13 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(double *__restrict_
       const v2d pl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p + i));
       double2 pv = make_double2(pl.x, pl.y);
 #else
-      double2 pv = *reinterpret_cast<double2 *>(p + i);
+      double2 pv = *reinterpret_cast<const double2 *>(p + i);
 #endif
 #if ABFT_CFG_X_NT  // x is touched once per iteration: keep it out of the caches (Infinity Cache included) that p, r, w could live in
       const v2d xl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(x + i));
       double2 xv = make_double2(xl.x, xl.y);
 #else
-      double2 xv = *reinterpret_cast<double2 *>(x + i);
+      double2 xv = *reinterpret_cast<const double2 *>(x + i);
 #endif
 #if ABFT_CFG_DEAD_NT & 2  // r is not read again before the next iteration's calc_r rewrites it
       const v2d rl = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(r + i));
@@ -2978,15 +2980,15 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(double *__restrict_
       pv.x = rv.x + beta * pv.x;
       pv.y = rv.y + beta * pv.y;
 #if ABFT_CFG_X_NT
-      __builtin_nontemporal_store(v2d{xv.x, xv.y}, reinterpret_cast<v2d *>(x + i));
+      __builtin_nontemporal_store(v2d{xv.x, xv.y}, reinterpret_cast<v2d *>(x_out + i));
 #else
-      *reinterpret_cast<double2 *>(x + i) = xv;
+      *reinterpret_cast<double2 *>(x_out + i) = xv;
 #endif
-      *reinterpret_cast<double2 *>(p + i) = pv;
+      *reinterpret_cast<double2 *>(p_out + i) = pv;
     } else {
       const double pv = p[i];
-      x[i] = x[i] + alpha * pv;
-      p[i] = r[i] + beta * pv;
+      x_out[i] = x[i] + alpha * pv;
+      p_out[i] = r[i] + beta * pv;
     }
   }
 }
@@ -3010,23 +3012,26 @@ __global__ __launch_bounds__(ABFT_BLOCK) void axpy_kernel(double *__restrict__ x
 }
 
 hipError_t launch_calc_r(double *r, const double *w, double alpha, const double *num, const double *den,
-                         double *alpha_out, int n, const ReduceOut &out, hipStream_t s) {
+                         double *alpha_out, int n, const ReduceOut &out, hipStream_t s, double *r_out) {
   const int nb = reduce_blocks(n);
-  if (aligned16(r, w))
-    hipLaunchKernelGGL(calc_r_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, r, w, alpha, num, den, alpha_out, n, out);
+  if (!r_out) r_out = r;
+  if (aligned16(r, w, r_out))
+    hipLaunchKernelGGL(calc_r_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, r, w, alpha, num, den, alpha_out, n, out, r_out);
   else
-    hipLaunchKernelGGL(calc_r_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, r, w, alpha, num, den, alpha_out, n, out);
+    hipLaunchKernelGGL(calc_r_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, r, w, alpha, num, den, alpha_out, n, out, r_out);
   return hipGetLastError();
 }
 
 hipError_t launch_calc_px(double *p, const double *r, double *x, double beta, const double *num, const double *den,
-                          double alpha, const double *alpha_ptr, int n, hipStream_t s) {
+                          double alpha, const double *alpha_ptr, int n, hipStream_t s, double *p_out, double *x_out) {
   if (n <= 0) return hipSuccess;
   const int nb = reduce_blocks(n);
-  if (aligned16(p, r, x))
-    hipLaunchKernelGGL(calc_px_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, x, beta, num, den, alpha, alpha_ptr, n);
+  if (!p_out) p_out = p;
+  if (!x_out) x_out = x;
+  if (aligned16(p, r, x) && aligned16(p_out, x_out))
+    hipLaunchKernelGGL(calc_px_kernel<2>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, x, beta, num, den, alpha, alpha_ptr, n, p_out, x_out);
   else
-    hipLaunchKernelGGL(calc_px_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, x, beta, num, den, alpha, alpha_ptr, n);
+    hipLaunchKernelGGL(calc_px_kernel<1>, dim3(nb), dim3(ABFT_BLOCK), 0, s, p, r, x, beta, num, den, alpha, alpha_ptr, n, p_out, x_out);
   return hipGetLastError();
 }
 
