@@ -234,6 +234,12 @@ def single(args):
             roof["measured_read_peak"] = probe["read_GBps"]
             roof["frac_of_measured_read"] = round(roof["achieved"] / rd, 4)
     rr_final = state["rr"]
+    # how the library ran the loop behind the unchanged API: iterations whose r and x / p halves it had run ahead of the
+    # caller's calc_xr / calc_p (include/abft_hip.h: abft_hip_speculation_stats; ABFT_HIP_SPECULATE=0 turns that off)
+    import ctypes
+    taken, dropped = ctypes.c_long(), ctypes.c_long()
+    capi.check(ctx.L.abft_hip_speculation_stats(ctx.h, ctypes.byref(taken), ctypes.byref(dropped)))
+    spec_stats = {"taken_over": taken.value, "dropped": dropped.value}
     ctx.close()
 
     # ---- the other single-GPU configurations, outside the headline's timed loop ----
@@ -293,7 +299,7 @@ def single(args):
                     "one_core": stats(one)})
         if args.extras and args.mode != "secded":
             cpu["secded"] = stats(baseline.time_cg(cols, rows, vals, n, "secded", max(per // 2, 2), runs=CPU_RUNS))
-    return dt, n, nnz, roof, kernels, cpu, probe, rr_final, extras, block_dt
+    return dt, n, nnz, roof, kernels, cpu, probe, rr_final, extras, block_dt, spec_stats
 
 
 def agree_codes(code):
@@ -474,7 +480,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic"}
     if args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1 and os.environ.get("ABFT_BENCH_SHARDED") != "1":
-        dt, n, nnz, roof, kernels, cpu, probe, rr, extras, block_dt = single(args)
+        dt, n, nnz, roof, kernels, cpu, probe, rr, extras, block_dt, spec_stats = single(args)
         out = dict(base)
         out.update({"value": round(args.steps / dt, 2), "ms_per_step": round(dt / args.steps * 1e3, 4),
                     "blocks": len(block_dt), "value_min": round(args.steps / max(block_dt), 2),
@@ -486,7 +492,8 @@ def main():
                                "N": n, "nnz": nnz, "format": args.fmt, "mode": args.mode, "parallelism": "1 GPU",
                                "rr_after_last_step": rr,
                                # every block restarts the solve: rr is the residual after warmup + steps iterations
-                               "iterations_per_block": args.warmup + args.steps},
+                               "iterations_per_block": args.warmup + args.steps,
+                               "speculated_iterations": spec_stats},
                     "roofline": roof, "cpu_baseline": cpu, "kernels": kernels})
         if probe:
             out["stream_probe"] = probe
