@@ -67,13 +67,13 @@ struct abft_hip_ctx {
   HostSlot *host_slot_dev = nullptr;  // its device alias
   // Speculation (cross-call fusion no. 3, round 4; the host-scalar loop of cg.cpp:97-112): once the library has
   // seen one iteration -- spmv(A,p,w), [dot(p,w)], calc_xr(x,r,p,w,alpha), calc_p(p,r,beta) -- it enqueues, right
-  // behind the NEXT spmv(A,p,w) and its fold, the r half and the x / p half of that iteration with alpha = rr / p.w
-  // and beta = rr_new / rr formed on the device, writing into SHADOW buffers.  When the caller's calc_xr / calc_p
+  // behind the NEXT spmv(A,p,w) and its fold, the r half of that iteration with alpha = rr / p.w formed on the device,
+  // writing into a SHADOW buffer, and -- once calc_xr has been taken over -- the x / p half (x in place, p into a shadow).  When the caller's calc_xr / calc_p
   // then arrive with the same vectors and bit-identical alpha / beta (the same IEEE quotients of the scalars it was
   // handed), the shadows are swapped in -- no kernel is launched, the GPU never waited for the host; anything else
-  // drops the shadows and runs the call as written.  Same bits either way.  ABFT_HIP_SPECULATE=0 turns it off.
+  // drops the shadows and runs the call as written.  Same bits either way.  Opt-in: ABFT_HIP_SPECULATE=1.
   struct {
-    bool enabled = true;
+    bool enabled = false;                 // opt-in (ABFT_HIP_SPECULATE=1): see DESIGN.md section 4 for what it measured
     bool learned = false;                 // x, r, p, w below are the vectors of the last complete iteration
     abft_hip_vector *x = nullptr, *r = nullptr, *p = nullptr, *w = nullptr;
     bool have_rr = false;                 // scal[rr_at] holds the scalar last handed to the caller (r.r), whose value is rr_host
@@ -82,7 +82,7 @@ struct abft_hip_ctx {
     int stage = 0;                        // 0: nothing in flight; 1: both halves enqueued; 2: r committed, x / p pending
     uint32_t seq_rr = 0;                  // sequence number of the speculated r.r
     double rr_new_host = 0.0;
-    double *shadow[3] = {nullptr, nullptr, nullptr};  // r, p, x
+    double *shadow[2] = {nullptr, nullptr};  // r, p
     int shadow_n = 0;
     double *scal = nullptr;               // device doubles: [0], [1] r.r (alternating), [2] p.w (+ their event counts behind: 6 doubles)
     long commits = 0, drops = 0;
@@ -198,9 +198,8 @@ static int flush_deferred(abft_hip_ctx *ctx) {
 // sees x or p in any state the unfused sequence would not have produced.
 static bool same_bits(double a, double b) { return memcmp(&a, &b, sizeof(a)) == 0; }
 
-// an in-flight speculation is void: its shadow buffers are never looked at again (stage 2: the committed r stays, the
-// x half it owed is the pending deferred update, which the caller's path applies like any other -- and the residual the
-// caller holds is the speculated one)
+// an in-flight speculation is void: its shadow buffers are never looked at again (stage 2: the committed r and the x
+// already updated in place stay -- calc_xr is done; what the caller holds as r.r is the speculated one)
 static void spec_drop(abft_hip_ctx *ctx) {
   auto &S = ctx->spec;
   if (S.stage) S.drops++;
@@ -1607,14 +1606,18 @@ extern "C" int abft_hip_calc_xr(abft_hip_ctx *ctx, abft_hip_vector *x, abft_hip_
     }
     take = take && same_bits(alpha, S.rr_host / ctx->fused.value);
     if (take) {
+      // enqueue the x / p half BEFORE waiting for r.r: x += alpha p in place (it is due now), p = r + beta p with
+      // beta = r.r_new / r.r formed on the device into the shadow (the caller has yet to name its beta)
+      {
+        double *rr = S.scal + 2 * S.rr_at, *rr_dev_new = S.scal + 2 * (1 - S.rr_at);
+        KernelTimer t(ctx, ABFT_K_CALC_P);
+        HIPCHK(launch_calc_px(p->d, S.shadow[0], x->d, 0.0, rr_dev_new, rr, 0.0, ctx->alpha_dev, x->n, ctx->stream, S.shadow[1],
+                              nullptr));
+      }
       double rr_new = 0.0;
       if (int rc = scalar_from_host_slot(ctx, S.seq_rr, &rr_new)) { spec_drop(ctx); return rc; }
       std::swap(r->d, S.shadow[0]);  // r is now what calc_r left in the shadow; its old buffer is the next shadow
       ctx->fused.valid = false;
-      // x += alpha p is owed exactly as after a deferred calc_xr: the speculated x / p half holds it (stage 2), and
-      // if the caller does something else first, the pending update is applied in place like any other
-      ctx->defer.active = true; ctx->defer.on_dev = true;
-      ctx->defer.x = x->d; ctx->defer.p = p->d; ctx->defer.n = x->n; ctx->defer.alpha = alpha;
       S.stage = 2;
       S.rr_new_host = rr_new;
       *result = rr_new;
@@ -1647,12 +1650,9 @@ extern "C" int abft_hip_calc_p(abft_hip_ctx *ctx, abft_hip_vector *p, const abft
   auto &S = ctx->spec;
   if (S.stage == 2) {
     // the speculated x / p half is this very call if it names p and r and beta is the quotient of the two residuals
-    const bool take = p == S.p && r == S.r && same_bits(beta, S.rr_new_host / S.rr_host) && ctx->defer.active &&
-                      ctx->defer.x == S.x->d && ctx->defer.p == p->d;
+    const bool take = p == S.p && r == S.r && same_bits(beta, S.rr_new_host / S.rr_host) && !ctx->defer.active;
     if (take) {
       std::swap(p->d, S.shadow[1]);
-      std::swap(S.x->d, S.shadow[2]);
-      ctx->defer.active = false;
       ctx->fused.valid = false;
       S.stage = 0;
       S.rr_at = 1 - S.rr_at;  // the speculated r.r is the residual the caller now holds
@@ -2232,11 +2232,9 @@ static int spec_launch(abft_hip_ctx *ctx, const abft_hip_vector *vec, const abft
     KernelTimer t(ctx, ABFT_K_CALC_XR);
     HIPCHK(launch_calc_r(S.r->d, S.w->d, 0.0, rr, pw, ctx->alpha_dev, n, o, ctx->stream, S.shadow[0]));
   }
-  {
-    KernelTimer t(ctx, ABFT_K_CALC_P);
-    HIPCHK(launch_calc_px(S.p->d, S.shadow[0], S.x->d, 0.0, rr_new, rr, 0.0, ctx->alpha_dev, n, ctx->stream, S.shadow[1],
-                          S.shadow[2]));
-  }
+  // (the x / p half follows when calc_xr has been taken over: from then on x += alpha p is DUE, so x is updated in
+  // place and only p -- whose beta the caller has yet to name -- goes to a shadow.  Both halves out of place from
+  // here cost calc_px 8-10 us: five address streams instead of three)
   S.stage = 1;
   S.seq_rr = o.seq;
   return ABFT_OK;

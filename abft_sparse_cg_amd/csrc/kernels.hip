@@ -2955,7 +2955,7 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(const double *p, co
   const long stride = (long)gridDim.x * ABFT_BLOCK * VEC;
   for (long i = ((long)blockIdx.x * ABFT_BLOCK + threadIdx.x) * VEC; i < n; i += stride) {
     if (VEC == 2 && i + 1 < n) {
-#if ABFT_CFG_X_NT || (ABFT_CFG_DEAD_NT & 6)
+#if ABFT_CFG_X_NT || (ABFT_CFG_DEAD_NT & 6) || ABFT_CFG_PX_OUT_NT
       typedef double v2d __attribute__((ext_vector_type(2)));
 #endif
 #if ABFT_CFG_DEAD_NT & 4  // the old p is dead after this read
@@ -2981,10 +2981,18 @@ __global__ __launch_bounds__(ABFT_BLOCK) void calc_px_kernel(const double *p, co
       pv.y = rv.y + beta * pv.y;
 #if ABFT_CFG_X_NT
       __builtin_nontemporal_store(v2d{xv.x, xv.y}, reinterpret_cast<v2d *>(x_out + i));
+#elif ABFT_CFG_PX_OUT_NT & 1
+      if (x_out != x) __builtin_nontemporal_store(v2d{xv.x, xv.y}, reinterpret_cast<v2d *>(x_out + i));
+      else *reinterpret_cast<double2 *>(x_out + i) = xv;
 #else
       *reinterpret_cast<double2 *>(x_out + i) = xv;
 #endif
+#if ABFT_CFG_PX_OUT_NT & 2
+      if (p_out != p) __builtin_nontemporal_store(v2d{pv.x, pv.y}, reinterpret_cast<v2d *>(p_out + i));
+      else *reinterpret_cast<double2 *>(p_out + i) = pv;
+#else
       *reinterpret_cast<double2 *>(p_out + i) = pv;
+#endif
     } else {
       const double pv = p[i];
       x_out[i] = x[i] + alpha * pv;

@@ -356,13 +356,14 @@ int abft_hip_matrix_panels(abft_hip_matrix *mat, int *npanels, int *width);
 int abft_hip_spmv_dot_range_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat, const abft_hip_vector *vec,
                                 abft_hip_vector *result, int vec_offset, double *dev_result, int c0, int c1);
 
-/* Speculation (round 4; cross-call fusion behind the unchanged host-scalar API, reference loop cg.cpp:97-112):
- * once the library has seen one iteration of the CG loop -- spmv(A,p,w), [dot(p,w)], calc_xr(x,r,p,w,alpha),
- * calc_p(p,r,beta) on vectors it alone can see -- it enqueues, right behind the next spmv(A,p,w), that iteration's r
- * half and x / p half with alpha = r.r / p.w and beta = r.r_new / r.r formed on the device, into shadow buffers;
- * when calc_xr / calc_p then arrive with the same vectors and bit-identical alpha / beta the shadows are swapped
- * in (no launch, no idle GPU while the scalars travel), anything else drops them and runs the call as written.
- * The results are the same bits either way.  ABFT_HIP_SPECULATE=0 turns it off; this reports how often a
+/* Speculation (round 4, opt-in: ABFT_HIP_SPECULATE=1; cross-call fusion behind the unchanged host-scalar API,
+ * reference loop cg.cpp:97-112): once the library has seen one iteration of the CG loop -- spmv(A,p,w), [dot(p,w)],
+ * calc_xr(x,r,p,w,alpha), calc_p(p,r,beta) on vectors it alone can see -- it enqueues, right behind the next
+ * spmv(A,p,w), that iteration's r half with alpha = r.r / p.w formed on the device, into a shadow buffer; a calc_xr
+ * that arrives with the same vectors and a bit-identical alpha takes it over (r's buffer and the shadow are swapped, no
+ * launch, the GPU did not wait for the scalar's round trip) and at once enqueues the x / p half (x in place -- it is
+ * due --, p with beta = r.r_new / r.r into a shadow), which calc_p takes over likewise; anything else drops the
+ * shadows and runs the call as written.  The results are the same bits either way.  This reports how often a
  * speculated iteration was taken over / dropped. */
 int abft_hip_speculation_stats(abft_hip_ctx *ctx, long *taken, long *dropped);
 

@@ -1,5 +1,5 @@
-"""Speculation behind the unchanged host-scalar API (include/abft_hip.h: abft_hip_speculation_stats; the reference
-loop cg.cpp:97-112): from the second iteration on the library runs the r half and the x / p half of an iteration
+"""Speculation behind the unchanged host-scalar API (opt-in, ABFT_HIP_SPECULATE=1; include/abft_hip.h:
+abft_hip_speculation_stats; the reference loop cg.cpp:97-112): from the second iteration on the library runs the r half and the x / p half of an iteration
 ahead of the caller's calc_xr / calc_p, into shadow buffers, and swaps them in when the calls arrive as predicted.
 Transparent: every vector and every scalar the same bits as with ABFT_HIP_SPECULATE=0, whatever the caller does
 between the calls -- the predicted continuation, another alpha or beta, a look at a vector in the middle, a stop
@@ -92,6 +92,8 @@ def test_speculation_keeps_out_of_the_way():
     """vectors the caller can see into (a raw device pointer handed out, a view) are never speculated on; destroying a
     vector forgets the learned iteration; the device-scalar loop and graph capture do not speculate"""
     import abft_sparse_cg_amd as amd
+    import os
+    os.environ["ABFT_HIP_SPECULATE"] = "1"
     mat = laplace5(40, 40)
     cols, rows, vals, n = mat
     ctx = amd.HIPContext("secded", "csr")
@@ -105,3 +107,4 @@ def test_speculation_keeps_out_of_the_way():
     it, rr = amd.cg_solve(ctx, A, b, x, r, p, w, max_itrs=12, conv_threshold=0.0)
     assert it == 12 and stats(ctx) == (0, 0)
     ctx.close()
+    del os.environ["ABFT_HIP_SPECULATE"]
