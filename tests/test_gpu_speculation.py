@@ -88,12 +88,11 @@ def test_speculated_iterations_leave_the_same_bits(fmt, mode, which, monkeypatch
             assert s1[0] >= 3 and s1[1] >= 1, (script, s1)  # the perturbed ones were dropped, the others taken over
 
 
-def test_speculation_keeps_out_of_the_way():
+def test_speculation_keeps_out_of_the_way(monkeypatch):
     """vectors the caller can see into (a raw device pointer handed out, a view) are never speculated on; destroying a
     vector forgets the learned iteration; the device-scalar loop and graph capture do not speculate"""
     import abft_sparse_cg_amd as amd
-    import os
-    os.environ["ABFT_HIP_SPECULATE"] = "1"
+    monkeypatch.setenv("ABFT_HIP_SPECULATE", "1")
     mat = laplace5(40, 40)
     cols, rows, vals, n = mat
     ctx = amd.HIPContext("secded", "csr")
@@ -107,4 +106,3 @@ def test_speculation_keeps_out_of_the_way():
     it, rr = amd.cg_solve(ctx, A, b, x, r, p, w, max_itrs=12, conv_threshold=0.0)
     assert it == 12 and stats(ctx) == (0, 0)
     ctx.close()
-    del os.environ["ABFT_HIP_SPECULATE"]
