@@ -162,6 +162,9 @@ struct CooDev {
 #ifndef ABFT_CFG_DEAD_NT
 #define ABFT_CFG_DEAD_NT 0  // non-temporal loads of values read for the last time this iteration: bit 0 w in calc_r, 1 r in calc_px, 2 p in calc_px
 #endif
+#ifndef ABFT_CFG_SWEEP_COUNTS_NT
+#define ABFT_CFG_SWEEP_COUNTS_NT 0  // sweep kernel: the per-(segment, row) counts by non-temporal loads
+#endif
 #ifndef ABFT_CFG_PX_OUT_NT
 #define ABFT_CFG_PX_OUT_NT 0  // calc_px writing into shadow buffers (speculation): non-temporal stores, bit 0 x, bit 1 p
 #endif

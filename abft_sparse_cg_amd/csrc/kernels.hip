@@ -1988,7 +1988,12 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
           if (RPT == 2) cw[0] = *reinterpret_cast<const uint16_t *>(cp);
           else {
 #pragma unroll
-            for (int k = 0; k < RPT / 4; k++) cw[k] = reinterpret_cast<const uint32_t *>(cp)[k];
+            for (int k = 0; k < RPT / 4; k++)
+#if ABFT_CFG_SWEEP_COUNTS_NT  // the counts are read once per SpMV, like the elements: keep them out of the way of x in L2
+              cw[k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cp) + k);
+#else
+              cw[k] = reinterpret_cast<const uint32_t *>(cp)[k];
+#endif
           }
         }
         uint32_t start[RPT];
@@ -3085,10 +3090,13 @@ __device__ __forceinline__ double quarter_sum(double v, double *s_w) {  // block
 //   [8]      arrivals of the chunk fold        [9] flag A (generation)        [10] flag B (generation)
 //   [12]     arrivals of phase B in one counter (host-memory board: ONE workgroup folds, the last to arrive)
 //   [16..23] base of [0..7] for this launch    [24] base of [8]    [25] generation of the previous launch    [27] base of [12]
-__device__ __forceinline__ bool tail_wait_ge64(const unsigned long long *word, unsigned long long want, unsigned long long ticks) {
+__device__ __forceinline__ bool tail_wait_ge64(unsigned long long *sync, uint32_t at, unsigned long long want, unsigned long long ticks) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
-  while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-    if ((unsigned long long)wall_clock64() - t0 > ticks) return false;
+  while (__hip_atomic_load(sync + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    if ((unsigned long long)wall_clock64() - t0 > ticks) {
+      __hip_atomic_store(sync + 30, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky: see cg_tail_kernel
+      return false;
+    }
     __builtin_amdgcn_s_sleep(1);
   }
   return true;
@@ -3096,7 +3104,7 @@ __device__ __forceinline__ bool tail_wait_ge64(const unsigned long long *word, u
 
 // all eight shards of the phase-B arrival counter have reached this launch's targets (the shards share one 64-byte
 // line); `want`: read from the bases BEFORE this workgroup's own arrival -- workgroup 0 rewrites the bases at its end
-__device__ __forceinline__ bool tail_wait_arrivals(const unsigned long long *sync, const unsigned long long *want,
+__device__ __forceinline__ bool tail_wait_arrivals(unsigned long long *sync, const unsigned long long *want,
                                                    unsigned long long ticks) {
   const unsigned long long t0 = (unsigned long long)wall_clock64();
   for (;;) {
@@ -3107,7 +3115,10 @@ __device__ __forceinline__ bool tail_wait_arrivals(const unsigned long long *syn
     if (c0.x >= want[0] && c0.y >= want[1] && c1.x >= want[2] && c1.y >= want[3] && c2.x >= want[4] && c2.y >= want[5] &&
         c3.x >= want[6] && c3.y >= want[7])
       return true;
-    if ((unsigned long long)wall_clock64() - t0 > ticks) return false;
+    if ((unsigned long long)wall_clock64() - t0 > ticks) {
+      __hip_atomic_store(sync + 30, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
     __builtin_amdgcn_s_sleep(1);
   }
 }
@@ -3204,7 +3215,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     if (a.fold_nb) {
       if (t == 0) {
         const uint32_t senders = min(gridDim.x, (a.fold_nb + 3u) / 4u);
-        s_last = tail_wait_ge64(sync + 8, sync[24] + senders, a.timeout_ticks) ? 1u : 0u;
+        s_last = tail_wait_ge64(sync, 8u, sync[24] + senders, a.timeout_ticks) ? 1u : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
       __syncthreads();
@@ -3250,12 +3261,15 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     }
   }
   if (!each_a && t == 0) {
-    const bool ok = tail_wait_ge64(sync + 9, gen, a.timeout_ticks);
+    const bool ok = tail_wait_ge64(sync, 9u, gen, a.timeout_ticks);
     const double pw = __hip_atomic_load(a.f.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_scal = ok ? pw : nan;
   }
   __syncthreads();
-  const double alpha = rr / s_scal;  // cg.cpp:102
+  // (a launch in which some workgroup gave up waiting leaves the counters short of what the bases say: from then on
+  // every launch on this context answers NaN -- loud -- instead of trusting them; sync[30] is never cleared)
+  const bool broken = __hip_atomic_load(sync + 30, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull;
+  const double alpha = broken ? nan : rr / s_scal;  // cg.cpp:102
   __syncthreads();  // (s_scal is written again below)
   TSTAMP(2);
 
@@ -3370,7 +3384,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   }
   __syncthreads();
   if (!each_b && t == 0) {
-    const bool ok = tail_wait_ge64(sync + 10, gen, a.timeout_ticks);
+    const bool ok = tail_wait_ge64(sync, 10u, gen, a.timeout_ticks);
     const double rn = __hip_atomic_load(a.o.dev_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_scal = ok ? rn : nan;
   }
