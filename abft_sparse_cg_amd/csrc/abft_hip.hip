@@ -57,7 +57,7 @@ struct abft_hip_ctx {
   unsigned long long *tail_sync = nullptr;  // cg_tail_kernel's hand-off words (device; they only ever grow)
   bool capturing = false;         // between abft_hip_graph_begin and _end
   bool tail_enabled = true;       // ABFT_HIP_TAIL=0: the iteration's tail as its three kernels
-  int tail_cap[3] = {-1, -1, -1}; // workgroups of cg_tail_kernel<1> / <2> / <2, fast> that are resident at once (asked once)
+  int tail_cap[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};  // [q: 1, 2, 4 blocks per workgroup][<1>, <2>, <2, fast>]: resident workgroups (asked once)
   int sharers = 1;                // processes that run this library on this device at the same time (abft_hip_set_sharers)
   uint32_t seq = 0;            // last sequence number handed to a reduction
   bool spin_wait = true;       // wait for scalars by polling the pinned slot
@@ -2445,17 +2445,25 @@ extern "C" int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat
   uint32_t grid = 0;
   const uint32_t nbv = (uint32_t)reduce_blocks(n);
   bool fast = false;
+  int q = 4;
   if (merged) {
+    // workgroups of q virtual blocks.  1024 threads (q = 4) at every length: smaller workgroups put one on more CUs for
+    // the mid-size vectors, but every grid-wide point then has that many more arrivals on one line of counters and
+    // pollers beside them -- measured, 1.25 M rows: 20 500 / 16 800 / 12 800 it/s with q = 4 / 2 / 1; 524 288 rows:
+    // 9 082 / 8 996 / 8 885 (profiles/r04/tail_ab.txt).  ABFT_HIP_TAIL_Q = 2 | 1 keeps the others reachable (tests).
+    q = 4;
+    if (const char *e = getenv("ABFT_HIP_TAIL_Q")) q = atoi(e) == 4 ? 4 : atoi(e) == 2 ? 2 : atoi(e) == 1 ? 1 : q;
+    const int qi = q == 4 ? 2 : q == 2 ? 1 : 0;
     auto cap_of = [&](int which) {
-      int &cap = ctx->tail_cap[which];
-      if (cap < 0) cap = cg_tail_blocks_per_cu(which >= 1, which == 2) * ctx->num_cus;
+      int &cap = ctx->tail_cap[qi][which];
+      if (cap < 0) cap = cg_tail_blocks_per_cu(which >= 1, which == 2, q) * ctx->num_cus;
       // the workgroups wait for each other (and, across ranks, for the peers' launches): ALL of them must be resident.
       // Several processes on one device (tests: ranks sharing the one GPU) each get their share of it, less a half
       // for whatever else those processes have in flight.
       return ctx->sharers > 1 ? cap / (2 * ctx->sharers) : cap;
     };
-    // the register-resident form: every workgroup exactly four virtual blocks, a thread's chain at most four pairs
-    const uint32_t want = (nbv + 3u) / 4u;
+    // the register-resident form: every workgroup exactly q virtual blocks, a thread's chain at most four pairs
+    const uint32_t want = (nbv + (uint32_t)q - 1u) / (uint32_t)q;
     fast = vec2 && !hold.fix.on && (long long)n <= (long long)nbv * 2048 && (int)want <= cap_of(2);  // (the COO fix-up rewrites entries of w: no early loads)
     grid = fast ? want : std::min<uint32_t>(want, (uint32_t)std::max(cap_of(vec2 ? 1 : 0), 0));
     merged = grid > 0;
@@ -2490,7 +2498,7 @@ extern "C" int abft_hip_cg_iteration_dev(abft_hip_ctx *ctx, abft_hip_matrix *mat
   a.sync = ctx->tail_sync;
   a.timeout_ticks = 500000000ull;  // 5 s of the 100 MHz wall clock
   KernelTimer t(ctx, ABFT_K_CALC_XR);
-  HIPCHK(launch_cg_tail(a, vec2, fast, grid, ctx->stream));
+  HIPCHK(launch_cg_tail(a, vec2, fast, q, grid, ctx->stream));
   return ABFT_OK;
 }
 

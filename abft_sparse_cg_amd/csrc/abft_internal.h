@@ -361,8 +361,8 @@ hipError_t launch_spmv_coo_lean(int mode, const CooDev &A, const CsrPanels &P, c
                                 const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
 hipError_t launch_spmv_coo_pc(int mode, const CooDev &A, const CsrPanels &P, const double *x, double *y, EventRing ev,
                               const FuseOut *fuse, uint32_t grid, uint32_t chunk, hipStream_t s);
-int cg_tail_blocks_per_cu(bool vec2, bool fast);
-hipError_t launch_cg_tail(const TailArgs &a, bool vec2, bool fast, uint32_t grid, hipStream_t s);
+int cg_tail_blocks_per_cu(bool vec2, bool fast, int q);  // q: virtual 256-thread blocks per workgroup (4, 2, 1)
+hipError_t launch_cg_tail(const TailArgs &a, bool vec2, bool fast, int q, uint32_t grid, hipStream_t s);
 
 int reduce_blocks(int n);
 hipError_t launch_dot(const double *a, const double *b, int n, const ReduceOut &out, hipStream_t s);

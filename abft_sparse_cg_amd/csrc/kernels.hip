@@ -3131,8 +3131,10 @@ __device__ __forceinline__ bool tail_wait_arrivals(unsigned long long *sync, con
 #else
 #define TSTAMP(k)
 #endif
-template <int VEC, bool FAST>
-__global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
+// Q: virtual 256-thread blocks per workgroup (4, 2 or 1: workgroups of 1024, 512 or 256 threads).  The host picks 4;
+// the smaller ones (more workgroups for mid-size vectors, more arrivals per grid-wide point) measured slower.
+template <int VEC, bool FAST, int Q>
+__global__ __launch_bounds__(256 * Q) void cg_tail_kernel(TailArgs a) {
   __shared__ double s_w[16];
   __shared__ double s_scal;
   __shared__ uint32_t s_last;
@@ -3158,7 +3160,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   // FAST: this thread's (at most four) pairs of r and w, on their way while p.w is being folded
   constexpr int NK = FAST ? 4 : 1;
   double2 rv[NK], wv[NK], pv[NK], xv[NK];
-  const uint32_t myvb = blockIdx.x * 4u + q;
+  const uint32_t myvb = blockIdx.x * (uint32_t)Q + q;
   const long i0 = ((long)myvb * ABFT_BLOCK + tq) * 2;
   if (FAST) {
 #pragma unroll
@@ -3186,7 +3188,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
   }
   if (a.fold_nb) {
     // many partials: chunks by the first fold_nb virtual blocks, as fold_partials_kernel's workgroups
-    for (uint32_t base = blockIdx.x * 4u; base < a.fold_nb; base += gridDim.x * 4u) {
+    for (uint32_t base = blockIdx.x * (uint32_t)Q; base < a.fold_nb; base += gridDim.x * (uint32_t)Q) {
       const uint32_t vb = base + q;
       double acc = 0.0;
       if (vb < a.fold_nb) {
@@ -3205,7 +3207,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       if (vb < a.fold_nb && tq == 0) __hip_atomic_store(a.o.partials + vb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
     }
-    if (blockIdx.x * 4u < a.fold_nb && t == 0) {
+    if (blockIdx.x * (uint32_t)Q < a.fold_nb && t == 0) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_fetch_add(sync + 8, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -3214,7 +3216,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     double tot = 0.0, evs = 0.0;
     if (a.fold_nb) {
       if (t == 0) {
-        const uint32_t senders = min(gridDim.x, (a.fold_nb + 3u) / 4u);
+        const uint32_t senders = min(gridDim.x, (a.fold_nb + (uint32_t)Q - 1u) / (uint32_t)Q);
         s_last = tail_wait_ge64(sync, 8u, sync[24] + senders, a.timeout_ticks) ? 1u : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       }
@@ -3225,20 +3227,25 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       tot = quarter_sum(acc, s_w);
       if (t == 0 && !s_last) tot = nan;
     } else {
-      // fuse_finalize_kernel's fold: fixed order, sixteen independent loads in flight per thread
-      double acc = 0.0;
-      for (uint32_t i = t; i < a.nparts; i += 16u * 1024u) {
-        double v[16];
+      // fuse_finalize_kernel's fold (1024 threads: fixed order, sixteen independent loads in flight per thread); a
+      // smaller workgroup plays 4 / Q of its threads each: the same sixteen wave sums, added in the same order
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          const uint32_t j = i + (uint32_t)k * 1024u;
-          v[k] = j < a.nparts ? a.f.partials[j] : 0.0;
+      for (int vt = 0; vt < 4 / Q; vt++) {
+        const uint32_t tv = t + (uint32_t)vt * (256u * Q);
+        double acc = 0.0;
+        for (uint32_t i = tv; i < a.nparts; i += 16u * 1024u) {
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            const uint32_t j = i + (uint32_t)k * 1024u;
+            v[k] = j < a.nparts ? a.f.partials[j] : 0.0;
+          }
+#pragma unroll
+          for (int k = 0; k < 16; k += 4) acc += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
         }
-#pragma unroll
-        for (int k = 0; k < 16; k += 4) acc += (v[k] + v[k + 1]) + (v[k + 2] + v[k + 3]);
+        acc = wave_sum(acc);
+        if ((t & 63u) == 63u) s_w[tv >> 6] = acc;
       }
-      acc = wave_sum(acc);
-      if ((t & 63u) == 63u) s_w[t >> 6] = acc;
       __syncthreads();
       if (t == 0)
         for (int k = 0; k < 16; k++) tot += s_w[k];
@@ -3294,7 +3301,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
     if (myvb < a.nbv && tq == 0) __hip_atomic_store(a.o.partials + myvb, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   } else {
-    for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
+    for (uint32_t base = blockIdx.x * (uint32_t)Q; base < a.nbv; base += gridDim.x * (uint32_t)Q) {
       const uint32_t vb = base + q;
       double acc = 0.0;
       if (vb < a.nbv) {
@@ -3409,7 +3416,7 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       }
     }
   } else {
-    for (uint32_t base = blockIdx.x * 4u; base < a.nbv; base += gridDim.x * 4u) {
+    for (uint32_t base = blockIdx.x * (uint32_t)Q; base < a.nbv; base += gridDim.x * (uint32_t)Q) {
       const uint32_t vb = base + q;
       if (vb >= a.nbv) continue;
       for (long i = ((long)vb * ABFT_BLOCK + tq) * VEC; i < a.n; i += stride) {
@@ -3438,25 +3445,33 @@ __global__ __launch_bounds__(1024) void cg_tail_kernel(TailArgs a) {
       for (uint32_t k = 0; k < 8u; k++) sync[16u + k] += (gridDim.x + 7u - k) / 8u;
     else
       sync[27] += gridDim.x;
-    if (a.fold_nb) sync[24] += min(gridDim.x, (a.fold_nb + 3u) / 4u);
+    if (a.fold_nb) sync[24] += min(gridDim.x, (a.fold_nb + (uint32_t)Q - 1u) / (uint32_t)Q);
     sync[25] = gen;
   }
 }
 
-int cg_tail_blocks_per_cu(bool vec2, bool fast) {
+template <int Q> static int cg_tail_occupancy(bool vec2, bool fast) {
   int n = 0;
   hipError_t e;
-  if (fast) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2, true>, 1024, 0);
-  else if (vec2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2, false>, 1024, 0);
-  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<1, false>, 1024, 0);
+  if (fast) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2, true, Q>, 256 * Q, 0);
+  else if (vec2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<2, false, Q>, 256 * Q, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, cg_tail_kernel<1, false, Q>, 256 * Q, 0);
   if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
 }
+int cg_tail_blocks_per_cu(bool vec2, bool fast, int q) {
+  return q == 4 ? cg_tail_occupancy<4>(vec2, fast) : q == 2 ? cg_tail_occupancy<2>(vec2, fast) : cg_tail_occupancy<1>(vec2, fast);
+}
 
-hipError_t launch_cg_tail(const TailArgs &a, bool vec2, bool fast, uint32_t grid, hipStream_t s) {
-  if (fast) hipLaunchKernelGGL((cg_tail_kernel<2, true>), dim3(grid), dim3(1024), 0, s, a);
-  else if (vec2) hipLaunchKernelGGL((cg_tail_kernel<2, false>), dim3(grid), dim3(1024), 0, s, a);
-  else hipLaunchKernelGGL((cg_tail_kernel<1, false>), dim3(grid), dim3(1024), 0, s, a);
+template <int Q> static void launch_cg_tail_q(const TailArgs &a, bool vec2, bool fast, uint32_t grid, hipStream_t s) {
+  if (fast) hipLaunchKernelGGL((cg_tail_kernel<2, true, Q>), dim3(grid), dim3(256 * Q), 0, s, a);
+  else if (vec2) hipLaunchKernelGGL((cg_tail_kernel<2, false, Q>), dim3(grid), dim3(256 * Q), 0, s, a);
+  else hipLaunchKernelGGL((cg_tail_kernel<1, false, Q>), dim3(grid), dim3(256 * Q), 0, s, a);
+}
+hipError_t launch_cg_tail(const TailArgs &a, bool vec2, bool fast, int q, uint32_t grid, hipStream_t s) {
+  if (q == 4) launch_cg_tail_q<4>(a, vec2, fast, grid, s);
+  else if (q == 2) launch_cg_tail_q<2>(a, vec2, fast, grid, s);
+  else launch_cg_tail_q<1>(a, vec2, fast, grid, s);
   return hipGetLastError();
 }
 

@@ -70,7 +70,8 @@ def run_iterations(amd, capi, fmt, mode, mat, iters, one_call, graph=False, flip
 
 CASES = [
     ("csr", "secded", "lap", None),      # streaming layout, a few hundred partials
-    ("csr", "none", "lap_big", None),    # 11 000 row blocks: the fold by chunks (fold_partials_kernel's shape)
+    ("csr", "none", "lap_big", None),    # 11 000 row blocks: the fold by chunks (fold_partials_kernel's shape); 1024-thread workgroups
+    ("csr", "sed", "lap_mid", None),     # 1.3 M rows: 512-thread workgroups (two virtual blocks each)
     ("csr", "sec8", "rand", None),       # sweep layout (forced below)
     ("coo", "sec7", "rand", None),       # COO, panel layout (forced)
     ("coo", "none", "lap", (777, [3])),  # a silently corrupted column: the fix-up runs inside the fold
@@ -85,6 +86,8 @@ def test_one_launch_tail_equals_the_three_kernels(fmt, mode, which, flip, monkey
         mat = laplace5(61, 47)          # n = 2867: odd, one virtual block only partly filled
     elif which == "lap_big":
         mat = laplace5(1500, 1501)
+    elif which == "lap_mid":
+        mat = laplace5(1150, 1151)
     else:
         mat = random_spd(30011, 9, seed=5)
         monkeypatch.setenv("ABFT_HIP_LAYOUT", "sweep" if fmt == "csr" else "panels")
@@ -101,6 +104,13 @@ def test_one_launch_tail_equals_the_three_kernels(fmt, mode, which, flip, monkey
     replay, _ = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=True, graph=True, flip=flip)
     for a, b in zip(three, replay):
         assert np.array_equal(bits(a), bits(b))
+    # every workgroup size on every case (the default picks one by the vector's length)
+    for q in ("1", "2", "4"):
+        monkeypatch.setenv("ABFT_HIP_TAIL_Q", q)
+        forced, _ = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=True, flip=flip)
+        for a, b in zip(three, forced):
+            assert np.array_equal(bits(a), bits(b)), q
+    monkeypatch.delenv("ABFT_HIP_TAIL_Q")
     # ABFT_HIP_TAIL=0: the same entry point runs the three kernels
     monkeypatch.setenv("ABFT_HIP_TAIL", "0")
     off, _ = run_iterations(amd, capi, fmt, mode, mat, iters, one_call=True, flip=flip)
