@@ -1064,18 +1064,24 @@ static int create_coo(abft_hip_ctx *ctx, int mode, const uint32_t *columns, cons
     return rc;
   }
   A.elems = d_el; A.grp_ptr = d_grp; A.blk = d_blk; A.orig_index = d_orig; A.pos_of_orig = d_pos;
-  if (mode == ABFT_MODE_CONSTRAINTS) {  // where each stored element's caller-order successor is stored
-    // (one entry more than elements: lanes past a tile's end read the entry of its first position,
-    // which for an empty tile at the end of the matrix is position nnz)
-    std::vector<uint32_t> succ((size_t)nnz + 1, 0xffffffffu);
-    for (int i = 0; i + 1 < nnz; i++) succ[pos[i]] = pos[i + 1];
-    uint32_t *d_succ = nullptr;
-    if ((rc = dev_upload(m, &d_succ, succ.data(), succ.size(), succ.size()))) {
+  if (mode == ABFT_MODE_CONSTRAINTS) {
+    // {col,row} of every stored element as it is now (kernels.hip, coo_constraints_cold); the complement for an
+    // element that fails the reference's checks already (COO/CPUContext.cpp:155-188), which is then checked on
+    // every pass.  (One entry more than elements: lanes past a tile's end read the entry of its first position,
+    // which for an empty tile at the end of the matrix is position nnz.)
+    std::vector<uint2> made((size_t)nnz + 1, make_uint2(0u, 0u));
+    for (int i = 0; i < nnz; i++) {
+      bool fails = rows[i] >= (uint32_t)n_in || columns[i] >= (uint32_t)n_out;
+      if (!fails && i + 1 < nnz) fails = rows[i] > rows[i + 1] || (rows[i] == rows[i + 1] && columns[i] >= columns[i + 1]);
+      made[pos[i]] = fails ? make_uint2(~columns[i], ~rows[i]) : make_uint2(columns[i], rows[i]);
+    }
+    uint2 *d_made = nullptr;
+    if ((rc = dev_upload(m, &d_made, made.data(), made.size(), made.size()))) {
       matrix_free(m);
       return rc;
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));  // `succ` goes out of scope
-    A.succ_pos = d_succ;
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // `made` goes out of scope
+    A.as_created = d_made;
   }
   if (panels) {
     uint32_t *d_segbase = nullptr;

@@ -135,7 +135,7 @@ struct CooDev {
   const uint4 *blk;             // nblk : {first group, end group, first element, end element}
   const uint32_t *orig_index;   // stored position -> caller's element index (cold path)
   const uint32_t *pos_of_orig;  // caller's element index -> stored position
-  const uint32_t *succ_pos;     // constraints mode: stored position of the caller-order successor (~0u: none)
+  const uint2 *as_created;      // constraints mode: {col,row} of every stored element as create_matrix left it (or its complement: see kernels.hip)
   uint32_t nblk, n_out, n_in, nnz, index_base;
   MovedList moved;
   const uint32_t *gidx;         // column-block shards: global (caller's) index of local element k; else index_base + k

@@ -828,8 +828,47 @@ hipError_t launch_spmv_csr(int mode, const CsrDev &A, const TileSpan &span, cons
 // output the reference adds the product to (COO/CPUContext.cpp:120, :224, :267, :320,
 // :376) -- so that the summing phase can tell an element whose column no longer names
 // the group it is stored in (see MovedList).
+// Constraints mode, COO (reference COO/CPUContext.cpp:155-188): element i of the CALLER's order is checked for its
+// sizes and against element i + 1 -- which the grouped storage keeps somewhere else: reading it for every element is
+// one HBM-served gather per element (rounds 2-3: 3.1-3.6 x the time of `none` on scattered matrices).  Instead:
+// the outcome of a pair's check can only differ from what it was at create time if one of its two elements has
+// changed since, and an element that has changed no longer equals the copy of its {col,row} taken then
+// (CooDev::as_created).  So the hot path compares each element with its copy, and an element that differs runs the
+// reference's checks on the words as STORED NOW for both pairs it is part of: its own chain (sizes, then the pair
+// with its successor), and its predecessor's pair with it -- unless the predecessor differs from its copy too and
+// therefore runs that pair itself.  Every pair with a changed member is checked exactly once, on the stored words;
+// a pair with none passes as it did at create time.  (An element whose checks FAIL at create time gets the
+// complement of its words as the copy: it never matches and is checked on every pass.)  A fault in the copy itself
+// costs a visit here and finds nothing: the verdicts only ever come from the matrix' own words.
+__device__ __forceinline__ bool coo_constraints_cold(const CooDev &A, const EventRing &ev, uint32_t j) {
+  const uint2 me = *reinterpret_cast<const uint2 *>(A.elems + j);
+  const uint32_t col = me.x, row = me.y, oi = A.orig_index[j];
+  int kind = 0;
+  if (row >= A.n_in) kind = ABFT_EV_ROW_SIZE;
+  else if (col >= A.n_out) kind = ABFT_EV_COL_SIZE;
+  else if (oi + 1u < A.nnz) {  // (the last element has no successor: COO/CPUContext.cpp:168)
+    const uint2 nx = *reinterpret_cast<const uint2 *>(A.elems + A.pos_of_orig[oi + 1u]);
+    if (row > nx.y) kind = ABFT_EV_ROW_ORDER;
+    else if (row == nx.y && col >= nx.x) kind = ABFT_EV_COL_ORDER;
+  }
+  if (kind) push_event(ev, (uint32_t)kind, event_index(A, j), 0, FMT_COO);
+  if (oi >= 1u) {
+    const uint32_t pj = A.pos_of_orig[oi - 1u];
+    const uint2 pe = *reinterpret_cast<const uint2 *>(A.elems + pj);
+    const uint2 pm = A.as_created[pj];
+    if (pe.x == pm.x && pe.y == pm.y) {  // an unchanged predecessor (its sizes hold, as at create time) does not come here itself
+      int pk = 0;
+      if (pe.y > row) pk = ABFT_EV_ROW_ORDER;
+      else if (pe.y == row && pe.x >= col) pk = ABFT_EV_COL_ORDER;
+      if (pk) push_event(ev, (uint32_t)pk, event_index(A, pj), 0, FMT_COO);
+    }
+  }
+  return kind == 0;
+}
+
 template <int EPT> struct CooTileRegs {
   u32x4 e[EPT];
+  u32x2 made[EPT];  // constraints mode: the elements' {col,row} as created (coo_constraints_cold); unused otherwise
 };
 
 // the streaming loads of one COO tile [lo, hi): out-of-tile lanes re-read its first element
@@ -839,6 +878,7 @@ __device__ __forceinline__ void coo_issue_loads(const CooDev &A, uint32_t lo, ui
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
     t.e[s] = STREAM_LOAD(reinterpret_cast<const u32x4 *>(A.elems + (j < hi ? j : lo)));
+    if (MODE == MODE_CONSTRAINTS) t.made[s] = STREAM_LOAD(reinterpret_cast<const u32x2 *>(A.as_created) + (j < hi ? j : lo));
   }
   // Keep every streaming load ahead of the first use.  Without this hipcc is free to put an element's
   // range check right behind its load -- and in `none`, where nothing else sits between them, it does:
@@ -858,46 +898,19 @@ __device__ __forceinline__ void coo_consume(const CooDev &A, const double *__res
   uint32_t row[EPT];
   double val[EPT];
   bool ok[EPT];
-  // constraints mode compares every element with its successor in the CALLER's order
-  // (reference COO/CPUContext.cpp:170-186), which sits somewhere else in the grouped storage:
-  // its stored position comes from a table built at create time (one coalesced 4-byte load per
-  // element; ~0u: no successor), then one 8-byte gather of its {col,row}.  Issued for the whole
-  // tile before any check, branch-free, so that the gathers run together.  (Through the two
-  // permutation arrays -- two dependent gathers per element -- this mode took 2.3x the time of
-  // every other one.)
-  uint2 nxt_cr[MODE == MODE_CONSTRAINTS ? EPT : 1];
-  bool has_nxt[MODE == MODE_CONSTRAINTS ? EPT : 1];
-  if (MODE == MODE_CONSTRAINTS) {
-    uint32_t sp[EPT];
-#pragma unroll
-    for (int s = 0; s < EPT; s++) {
-      const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
-      sp[s] = A.succ_pos[j < hi ? j : lo];
-    }
-#pragma unroll
-    for (int s = 0; s < EPT; s++) {
-      has_nxt[s] = sp[s] != 0xffffffffu;
-      nxt_cr[s] = *reinterpret_cast<const uint2 *>(A.elems + (has_nxt[s] ? sp[s] : lo));
-    }
-  }
+  uint32_t changed = 0u;  // constraints mode: bit s = element s of this lane differs from its copy
+  // constraints mode compares every element with its successor in the CALLER's order (reference
+  // COO/CPUContext.cpp:170-186), which sits somewhere else in the grouped storage: see coo_constraints_cold.
+  // Hot path: the element's {col,row} against what create_matrix stored (one coalesced 8-byte load beside the element's).
 #pragma unroll
   for (int s = 0; s < EPT; s++) {
     const uint32_t j = lo + threadIdx.x + (uint32_t)s * ABFT_BLOCK;
     uint32_t w[4] = {t.e[s].x, t.e[s].y, t.e[s].z, t.e[s].w};
     bool valid = j < hi;
     if (MODE == MODE_CONSTRAINTS) {
-      if (valid) {
-        const uint32_t ncol = nxt_cr[s].x, nrow = nxt_cr[s].y;
-        int kind = 0;
-        if (w[1] >= A.n_in) kind = ABFT_EV_ROW_SIZE;
-        else if (w[0] >= A.n_out) kind = ABFT_EV_COL_SIZE;
-        else if (has_nxt[s] && w[1] > nrow) kind = ABFT_EV_ROW_ORDER;
-        else if (has_nxt[s] && w[1] == nrow && w[0] >= ncol) kind = ABFT_EV_COL_ORDER;
-        if (__builtin_expect(kind != 0, 0)) {
-          push_event(ev, (uint32_t)kind, event_index(A, j), 0, FMT_COO);
-          valid = false;
-        }
-      }
+      // (only noted here: the checks run behind the LDS writes, where nothing of the tile is live any more -- with
+      // them, or a call to them, in this loop the kernel took 565 instead of 267 us on the 5-point Laplacian)
+      if (valid && (w[0] != t.made[s].x || w[1] != t.made[s].y)) changed |= 1u << s;
     } else if (MODE >= MODE_SED) {
       if (__builtin_expect(valid && ecc_suspect<FMT_COO, MODE>(w) != 0, 0)) {
         EccWords<FMT_COO> ce;
@@ -930,6 +943,16 @@ __device__ __forceinline__ void coo_consume(const CooDev &A, const double *__res
     const double p = val[s] * xv[s];
     s_prod[threadIdx.x + (uint32_t)s * ABFT_BLOCK] = ok[s] ? p : 0.0;
   }
+#ifndef ABFT_DBG_NOCOLD  // (timing-only build without the checks of changed elements)
+  if (MODE == MODE_CONSTRAINTS && __builtin_expect(changed != 0u, 0)) {
+#pragma unroll 1
+    for (uint32_t s = 0; s < (uint32_t)EPT; s++) {
+      if (!((changed >> s) & 1u)) continue;
+      // (an element that violates a constraint contributes nothing: the reference has stopped in front of it)
+      if (!coo_constraints_cold(A, ev, lo + threadIdx.x + s * ABFT_BLOCK)) s_prod[threadIdx.x + s * ABFT_BLOCK] = 0.0;
+    }
+  }
+#endif
 }
 
 template <int MODE, int EPT>

@@ -224,6 +224,72 @@ def test_constraints_mode_detects_like_reference(amd, fmt, layout, monkeypatch):
     assert fatal_seen > 20
 
 
+@pytest.mark.parametrize("layout", ["stream", "panels"])
+def test_coo_constraints_pairs_with_changed_members(amd, layout, monkeypatch):
+    """Round 4: the COO constraints check no longer reads every element's caller-order successor (one HBM gather
+    per element) -- an element is compared with the copy of its {col,row} taken at create time, and only one that
+    differs runs the reference's checks (COO/CPUContext.cpp:155-188), for both pairs it is a member of.  What
+    that has to get right: flips in NEIGHBOURING elements of the caller's order (a pair both of whose members
+    changed is checked once, by the first), a changed last / first element, a flip undone again, and a matrix
+    that violates the order as created (no flips at all).  Events as the oracle's; y where nothing is fatal."""
+    monkeypatch.setenv("ABFT_HIP_LAYOUT", layout)
+    monkeypatch.setenv("ABFT_HIP_PANEL_WIDTH", "16")
+    monkeypatch.setenv("ABFT_HIP_PANEL_CHUNK", "2")
+    cols, rows, vals, n = random_spd(60, 7, seed=9)
+    nnz = len(vals)
+    x = rhs(n, 3)
+    rng = np.random.default_rng(5)
+
+    def compare(o, h, tag):
+        fatal = False
+        for _ in range(2):
+            y, want = h.spmv(x), o.spmv(x)
+            ev, fatal = h.take_events()
+            assert (ev, fatal) == o.events(), tag
+            if fatal:
+                break
+            assert bits_equal(y, want), tag
+        return fatal
+
+    fatal_seen = passed = 0
+    for trial in range(120):
+        o = OracleMatrix(COO, "constraints", cols, rows, vals, n)
+        h = Hip(amd, COO, "constraints", cols, rows, vals, n)
+        try:
+            k = int(rng.choice([0, nnz - 3, int(rng.integers(0, nnz - 3))]))
+            members = sorted(set(int(k + d) for d in rng.choice(3, size=int(rng.integers(1, 4)))))
+            flips = []
+            for i in members:
+                word = int(rng.integers(0, 2))  # the column word or the row word
+                flips.append((i, [32 * word + int(rng.integers(0, 5))]))
+            for i, bits in flips:
+                o.inject(i, bits)
+                h.ctx.inject_at(h.A, i, bits)
+            f = compare(o, h, (trial, flips))
+            fatal_seen += f
+            passed += not f
+            if not f and trial % 3 == 0:  # ... and undone: nothing differs from its copy any more
+                for i, bits in flips:
+                    o.inject(i, bits)
+                    h.ctx.inject_at(h.A, i, bits)
+                assert not compare(o, h, (trial, "undone"))
+        finally:
+            h.close()
+    assert fatal_seen >= 30 and passed >= 10, (fatal_seen, passed)
+    # as created: two neighbours of the caller's order exchanged (the first pair check fails on every pass, no flip)
+    for k in (0, nnz // 2, nnz - 2):
+        c2, r2, v2 = cols.copy(), rows.copy(), vals.copy()
+        for a in (c2, r2, v2):
+            a[[k, k + 1]] = a[[k + 1, k]]
+        o = OracleMatrix(COO, "constraints", c2, r2, v2, n)
+        h = Hip(amd, COO, "constraints", c2, r2, v2, n)
+        try:
+            assert compare(o, h, ("created", k))
+            assert compare(o, h, ("created again", k))
+        finally:
+            h.close()
+
+
 @pytest.mark.parametrize("width,rpt,lag", [(16, 8, 2), (7, 2, 0), (64, 4, 1), (100000, 8, 2)])
 def test_constraints_mode_in_the_sweep_layout(amd, width, rpt, lag, monkeypatch):
     """Round 3: constraints mode runs on the sweep layout too (scattered matrices; round 2 forced the

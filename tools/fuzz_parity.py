@@ -66,6 +66,9 @@ def one_case(seed):
     nnz = len(vals)
     fmt = CSR if rng.random() < 0.6 else COO
     mode = str(rng.choice(MODES))
+    if os.environ.get("ABFT_FUZZ_ONLY"):  # e.g. coo:constraints -- a campaign on one format and mode
+        f, mode = os.environ["ABFT_FUZZ_ONLY"].split(":")
+        fmt = COO if f == "coo" else CSR
     layout = str(rng.choice(["stream", "panels", "sweep", "slice", "slice", "auto"]))
     os.environ["ABFT_HIP_SLICE_ROWS"] = str(int(rng.choice([16, 64, 256, 1024])))
     os.environ["ABFT_HIP_SLICE_LAG"] = str(int(rng.choice([0, 1, 2, 3])))
@@ -85,8 +88,11 @@ def one_case(seed):
     os.environ["ABFT_HIP_PANEL_XPF"] = str(int(rng.integers(0, 2)))
     flips = []
     if nnz and (mode not in ("none", "constraints") or rng.random() < 0.7):
+        near = int(rng.integers(0, nnz))
         for _ in range(int(rng.integers(0, 4))):
             idx = int(rng.integers(0, nnz))
+            if rng.random() < 0.3:  # neighbours in the caller's order (the constraints checks compare those)
+                idx = min(nnz - 1, near + int(rng.integers(0, 3)))
             nb = 1 if rng.random() < 0.7 else 2
             if fmt == COO and rng.random() < 0.5:
                 # low column bits: the element lands in another output of the vector (the
