@@ -92,7 +92,9 @@ def one_case(seed):
                 model[w] = o.spmv(model[p])
                 want_pw = float(np.dot(model[p], model[w]))
                 if not abs(got[4] - want_pw) <= 1e-12 * float(np.abs(model[p] * model[w]).sum()) + 1e-300:
-                    return "seed %d step %d %s: devstep p.w %r vs %r" % (seed, step, trace[-6:], got[4], want_pw)
+                    # (the model's value computed a second time: a difference between the two is the checker's, not the device's)
+                    again = float(np.dot(model[p], o.spmv(model[p])))
+                    return "seed %d step %d %s: devstep p.w %r vs %r (model recomputed: %r)" % (seed, step, trace[-6:], got[4], want_pw, again)
                 with np.errstate(all="ignore"):
                     alpha = np.float64(cur) / np.float64(got[4])
                     model[x] = model[x] + alpha * model[p]
