@@ -743,12 +743,17 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_csr_panels_kernel(CsrDev A, C
         lo = hi;
       }
     }
+    double xo[FUSE ? RPT : 1];  // (the fused product's operands, in flight together)
+    if (FUSE) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) xo[j] = x[fuse.x_off + min(row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x, A.n_out - 1u)];
+    }
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t row = row0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
       if (row < A.n_out) {
         y[row] = acc[j];
-        if (FUSE) dsum += x[fuse.x_off + row] * acc[j];
+        if (FUSE) dsum += xo[j] * acc[j];
       }
     }
   }
@@ -1433,12 +1438,19 @@ __global__ __launch_bounds__(ABFT_BLOCK) void spmv_coo_panels_kernel(CooDev A, C
       if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;  // plain store: into this XCD's L2
     }
     STAMP(t_q0);
+    // (the fused product's operands first, all in flight together: read inside the loop below hipcc waits for each
+    // before it issues the next -- RPT trips to memory in a row at the end of every workgroup)
+    double xo[FUSE ? RPT : 1];
+    if (FUSE) {
+#pragma unroll
+      for (int j = 0; j < RPT; j++) xo[j] = x[fuse.x_off + min(out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x, A.n_out - 1u)];
+    }
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + (uint32_t)j * ABFT_BLOCK + threadIdx.x;
       if (o < A.n_out) {
         y[o] = acc[j];
-        if (FUSE) dsum += x[fuse.x_off + o] * acc[j];
+        if (FUSE) dsum += xo[j] * acc[j];
       }
     }
     STAMP(t_q1);
@@ -2166,12 +2178,17 @@ __global__ __launch_bounds__(ABFT_BLOCK, (RPT == 16 || MODE == MODE_CONSTRAINTS)
       }
       if (pace && threadIdx.x == 0 && my_slot < PACE_SLOTS) board[my_slot] = step + 1u;  // plain store: into this XCD's L2
     }
+    // (the fused product's operands first, all in flight together: read inside the loop below hipcc waits for each
+    // before it issues the next -- RPT trips to memory in a row at the end of every workgroup)
+    double xo[RPT];
+#pragma unroll
+    for (int j = 0; j < RPT; j++) xo[j] = fused ? x[fuse.x_off + min(out0 + 64u * (uint32_t)j, A.n_out - 1u)] : 0.0;
 #pragma unroll
     for (int j = 0; j < RPT; j++) {
       const uint32_t o = out0 + 64u * (uint32_t)j;
       if (o < A.n_out && !(CONS && cons_lp1[CONS ? j : 0] == 0xffffffffu)) {  // (a row that failed a check is left alone, as in the streaming kernel)
         y[o] = acc[j];
-        if (fused) dsum += x[fuse.x_off + o] * acc[j];
+        if (fused) dsum += xo[j] * acc[j];
       }
     }
   }
