@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "abft_internal.h"
@@ -475,6 +476,32 @@ static void matrix_free(abft_hip_matrix *m) {
             for (int x = 0; x < 8; x++)
               if (n_xcd[x] > 0) fprintf(stderr, " %.3f", mx_xcd[x] / (by_xcd[x] / n_xcd[x]));
             fprintf(stderr, "\n");
+            // how the dispatcher dealt the workgroups to the CUs (HW_ID of the LAST launch: CU_ID [11:8], SH_ID [12],
+            // SE_ID [15:13]) and the busy time by the number of workgroups that shared the CU
+            std::map<uint32_t, int> per_cu;
+            for (uint32_t g = 0; g < ng; g++)
+              if (w[4u * g]) per_cu[(uint32_t)((w[4u * g + 3] >> 32) & 7u) << 8 | (uint32_t)((w[4u * g + 3] >> 8) & 0xffu)]++;
+            double tsum[16] = {0}, tn[16] = {0};
+            int cus[16] = {0};
+            for (auto &kv : per_cu) cus[std::min(kv.second, 15)]++;
+            for (uint32_t g = 0; g < ng; g++) {
+              if (!w[4u * g]) continue;
+              const int k = std::min(per_cu[(uint32_t)((w[4u * g + 3] >> 32) & 7u) << 8 | (uint32_t)((w[4u * g + 3] >> 8) & 0xffu)], 15);
+              tsum[k] += (double)(w[4u * g] - w[4u * g + 1]); tn[k] += 1.0;
+            }
+            if (const char *path = getenv("ABFT_HIP_SWEEP_DEBUG_DUMP")) {  // one line per workgroup, for offline analysis
+              if (FILE *f = fopen(path, "w")) {
+                fprintf(f, "block,xcc,hw_id,total,pacing,staging\n");
+                for (uint32_t g = 0; g < ng; g++)
+                  fprintf(f, "%u,%u,%u,%llu,%llu,%llu\n", g, (unsigned)((w[4u * g + 3] >> 32) & 7u), (unsigned)(w[4u * g + 3] & 0xffffffffu),
+                          w[4u * g], w[4u * g + 1], w[4u * g + 2]);
+                fclose(f);
+              }
+            }
+            fprintf(stderr, "  workgroups per CU (last launch) -> CUs, mean busy clocks / median:");
+            for (int k = 1; k < 16; k++)
+              if (cus[k]) fprintf(stderr, "  %d: %d CUs %.3f", k, cus[k], tsum[k] / tn[k] / busy[n / 2]);
+            fprintf(stderr, " (%zu CUs in use)\n", per_cu.size());
           }
         }
       }
