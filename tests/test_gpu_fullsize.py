@@ -239,6 +239,44 @@ def test_config5_powerlaw_coo_sec7_full_size(amd, gen):
         k.close()
 
 
+def test_config5_matrix_coo_constraints_full_size(amd, gen):
+    """Round 4: cg-coo -m constraints on config 5's matrix (panel layout, one paced launch).  The hot path compares every
+    element with its create-time copy; a changed one runs the reference's checks (COO/CPUContext.cpp:155-188) on the
+    stored words.  Whole vector against the oracle; a value-bit flip (no constraint sees it: the product changes, in both);
+    index flips that keep / break the order, in neighbouring elements of the caller's order."""
+    mat = gen.generate("powerlaw:2097152,2")
+    cols, rows, vals, n = mat
+    nnz = len(vals)
+    x = np.random.default_rng(17).standard_normal(n)
+    c = Run(amd, "coo", "constraints", mat)
+    o = OracleMatrix(COO, "constraints", cols, rows, vals, n)
+    try:
+        assert c.ctx.matrix_info(c.A)[0] == "panels"
+        assert bits_equal(c.spmv(x), o.spmv(x)) and c.events == [] and o.events() == ([], False)
+        for index, bits in ((12345678, [77]), (nnz - 1, [64 + 52])):  # value bits
+            c.ctx.inject_at(c.A, index, bits)
+            o.inject(index, bits)
+        assert bits_equal(c.spmv(x), o.spmv(x)) and c.events == [] and o.events() == ([], False)
+        # an element whose successor in its row is far away: raising its column by one keeps the order -- the product moves
+        # to the next output, as in the reference (the copy differs, the checks pass)
+        k = next(i for i in range(5000000, nnz - 1) if rows[i] == rows[i + 1] and cols[i + 1] > cols[i] + 2 and not cols[i] & 1)
+        c.ctx.inject_at(c.A, k, [0])
+        o.inject(k, [0])
+        assert bits_equal(c.spmv(x), o.spmv(x)) and c.events == [] and o.events() == ([], False)
+        # ... and two neighbours changed at once, the first one out of order: one event, at the lower index, as the reference stops there
+        c.ctx.inject_at(c.A, k + 1, [31])  # column beyond the matrix
+        o.inject(k + 1, [31])
+        c.ctx.inject_at(c.A, k, [32 + 20])  # row far up: above its successor's
+        o.inject(k, [32 + 20])
+        c.spmv(x)
+        o.spmv(x)
+        ev_o, fatal_o = o.events()
+        assert fatal_o and c.events[:1] == ev_o[:1] and ev_o[0][1] in (k - 1, k)
+    finally:
+        c.close()
+        o.close()
+
+
 def test_panel_layout_on_config2_matches_streaming_layout(amd, gen, monkeypatch):
     """10 M rows = 4 883 output groups of the panel kernels (more workgroups than
     the fused-dot fold's first block): y and the fused p.w must equal the streaming
