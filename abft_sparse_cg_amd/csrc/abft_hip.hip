@@ -13,6 +13,7 @@
 #include <new>
 #include <thread>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "abft_internal.h"
@@ -274,6 +275,56 @@ struct KernelTimer {
 
 // ------------------------------------------------------------------ context --
 
+// A context's stream is NOT destroyed when the context ends: it goes, idle, into a process-wide pool (per device) and
+// the next context takes it from there.  Reason (round 4; tools/fuzz_sequence.py with ABFT_FUZZ_SEQ_MIX=1
+// ABFT_FUZZ_SEQ_WATCH=1, profiles/r04/stream_destroy_hunt.txt): in a process that creates and destroys contexts by the
+// ten thousand, hipStreamDestroy is followed -- milliseconds later, during the next context's calls -- by an increment
+// or decrement of one 32-bit word and a store of 0 to another inside a heap block of 913-928 bytes that malloc has
+// meanwhile handed to somebody else: the runtime still counts references on the stream object it has freed.  Seen as
+// two changed words, always at byte offsets 152 and 888, in the CPU checker's 916-byte row-pointer array (up to 15
+// times per 10 000 sequences; the device's results were right every time, the checker's were not); never once in
+// 20 000 sequences with the stream kept, whatever else was or was not released.  Not something this library can
+// repair inside ROCm 7.2's runtime; a stream per context that ever lived at the same time is the price of staying out
+// of its way.  (ABFT_HIP_DEBUG_LEAK=S restores the destroy, for reproducing it.)
+static bool debug_leak(char what);
+static std::mutex g_stream_mutex;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;  // (device, idle stream)
+
+static hipStream_t pooled_stream_take(int device) {
+  {
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    for (size_t i = 0; i < g_stream_pool.size(); i++)
+      if (g_stream_pool[i].first == device) {
+        hipStream_t s = g_stream_pool[i].second;
+        g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+        return s;
+      }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return s;
+}
+
+static void pooled_stream_give_back(int device, hipStream_t s) {
+  if (!s) return;
+  if (debug_leak('S')) {
+    (void)hipStreamDestroy(s);
+    return;
+  }
+  std::lock_guard<std::mutex> lock(g_stream_mutex);
+  g_stream_pool.emplace_back(device, s);
+}
+
+// ABFT_HIP_DEBUG_LEAK (hunting a use-after-free inside the HIP runtime that shows up as heap corruption of the HOST process
+// when contexts are created and destroyed by the ten thousand): letters name what is deliberately NOT released --
+// h: its pinned result slots, v: the vectors' pinned staging, d: a device synchronize first; S: the stream IS destroyed,
+// as it was before the pool above
+static bool debug_leak(char what) {
+  static const char *e = getenv("ABFT_HIP_DEBUG_LEAK");
+  return e && strchr(e, what);
+}
+
+
 extern "C" int abft_hip_device_count(int *count) {
   if (!count) return set_err(ABFT_ERR_INVALID, "null count");
   int n = 0;
@@ -305,7 +356,8 @@ extern "C" int abft_hip_init(int device, abft_hip_ctx **out) {
   if (!ctx) return set_err(ABFT_ERR_NOMEM, "context allocation failed");
   ctx->device = device;
   ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  HIPCHK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+  ctx->own_stream = pooled_stream_take(device);
+  if (!ctx->own_stream) return set_err(ABFT_ERR_HIP, "hipStreamCreateWithFlags failed");
   ctx->stream = ctx->own_stream;
   HIPCHK(hipMalloc((void **)&ctx->partials, ABFT_MAX_PARTIALS * sizeof(double)));
   HIPCHK(hipMalloc((void **)&ctx->ticket, ABFT_TICKET_WORDS * sizeof(uint32_t)));
@@ -356,6 +408,7 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)flush_deferred(ctx);
   (void)hipStreamSynchronize(ctx->stream);
+  if (debug_leak('d')) (void)hipDeviceSynchronize();
   for (int k = 0; k < ABFT_K_COUNT; k++) KernelTimer::fold(ctx, k);
   for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
   (void)hipFree(ctx->partials);
@@ -374,7 +427,7 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
     fprintf(stderr, "hip: speculated iterations: %ld taken over, %ld dropped\n", ctx->spec.commits, ctx->spec.drops);
   for (double *b : ctx->spec.shadow) (void)hipFree(b);
   (void)hipFree(ctx->spec.scal);
-  (void)hipHostFree(ctx->host_slot);
+  if (!debug_leak('h')) (void)hipHostFree(ctx->host_slot);
   (void)hipFree(ctx->ring.buf);
   (void)hipFree(ctx->ring.count);
   (void)hipFree(ctx->moved.buf);
@@ -382,7 +435,8 @@ extern "C" int abft_hip_shutdown(abft_hip_ctx *ctx) {
   (void)hipFree(ctx->bits_dev);
   (void)abft_hip_peer_board_detach(ctx);
   (void)abft_hip_peer_exchange_detach(ctx);
-  (void)hipStreamDestroy(ctx->own_stream);
+  (void)hipStreamSynchronize(ctx->own_stream);
+  pooled_stream_give_back(ctx->device, ctx->own_stream);
   delete ctx;
   return ABFT_OK;
 }
@@ -1431,7 +1485,7 @@ extern "C" int abft_hip_vector_destroy(abft_hip_vector *vec) {
   spec_forget(vec->ctx);  // (the learned iteration names vectors by handle)
   HIPCHK(hipStreamSynchronize(vec->ctx->stream));
   if (!vec->owns && vec->root) vec->root->views--;
-  if (vec->host) (void)hipHostFree(vec->host);
+  if (vec->host && !debug_leak('v')) (void)hipHostFree(vec->host);
   if (vec->owns) (void)hipFree(vec->d);
   delete vec;
   return ABFT_OK;

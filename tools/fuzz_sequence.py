@@ -27,7 +27,13 @@ def bits_equal(a, b):
 
 def one_case(seed):
     rng = np.random.default_rng(seed)
-    if rng.random() < 0.5:
+    if os.environ.get("ABFT_FUZZ_SEQ_GRID"):  # e.g. 12,19: every case on that Laplacian (hunting a size-specific failure)
+        g, h = (int(v) for v in os.environ["ABFT_FUZZ_SEQ_GRID"].split(","))
+        cols, rows, vals, n = laplace5(g, h)
+    elif os.environ.get("ABFT_FUZZ_SEQ_MIX") and seed % 2 == 0:  # every other case one of the sizes the failures were seen on
+        g, h = [(38, 6), (12, 19), (6, 38), (18, 3)][(seed // 2) % 4]
+        cols, rows, vals, n = laplace5(g, h)
+    elif rng.random() < 0.5:
         g = int(rng.integers(3, 40))
         cols, rows, vals, n = laplace5(g, int(rng.integers(3, 40)))
     else:
@@ -44,10 +50,36 @@ def one_case(seed):
         for d, m in zip(dev, model):
             ctx.upload(d, m)
         trace = []
+
+        def whose(p, w):
+            """a scalar differs: the model's pieces computed again, the oracle's stored matrix against its input, the device's vectors"""
+            w2 = o.spmv(model[p])
+            oc, orp, ov = o.csr_arrays()
+            o2 = OracleMatrix(CSR, mode, cols, rows, vals, n)
+            w3 = o2.spmv(model[p])
+            dw, dp = ctx.download(dev[w]), ctx.download(dev[p])
+            bad = np.nonzero(np.asarray(model[w]).view(np.uint64) != np.asarray(w3).view(np.uint64))[0]
+            return ("model again: dot %r; spmv again equals the model's w: %s (dot %r); a fresh oracle's: %s (dot %r, %d entries differ, first %s); "
+                    "device w equals model w %s / the fresh oracle's %s; device p equals model p %s; the oracle's arrays intact: %s"
+                    % (float(np.dot(model[p], model[w])), bits_equal(w2, model[w]), float(np.dot(model[p], w2)), bits_equal(w3, model[w]),
+                       float(np.dot(model[p], w3)), len(bad), bad[:4], bits_equal(dw, model[w]), bits_equal(dw, w3), bits_equal(dp, model[p]),
+                       bool(np.array_equal(oc & 0xFFFFFF, cols) and np.array_equal(o2.csr_arrays()[2], ov) and np.array_equal(o2.csr_arrays()[1], orp))))
+
+        watch = os.environ.get("ABFT_FUZZ_SEQ_WATCH") == "1"  # the checker's own matrix compared with its first image after every operation
+        image = o.csr_arrays() if watch else None
+        last_op = "create"
         for step in range(int(rng.integers(10, 60))):
+            if watch:
+                now = o.csr_arrays()
+                for name, a, b in zip(("cols", "rowptr", "values"), image, now):
+                    if not np.array_equal(a.view(np.uint32), b.view(np.uint32)):
+                        d = np.nonzero(a.view(np.uint32) != b.view(np.uint32))[0]
+                        return ("seed %d step %d: the ORACLE's %s changed behind %s (n %d, nnz %d, mode %s): words %s were %s are %s"
+                                % (seed, step, name, last_op, n, len(vals), mode, d[:8], a.view(np.uint32)[d[:8]], b.view(np.uint32)[d[:8]]))
             op = str(rng.choice(["spmv", "dot", "calc_xr", "calc_p", "copy", "download", "upload", "cgstep", "devstep"]))
             ids = [int(i) for i in rng.permutation(NV)]
             trace.append((op, ids[:4]))
+            last_op = "%s %s (after %s)" % (op, ids[:4], trace[-3:-1])
             if op == "spmv":
                 a, b = ids[:2]
                 ctx.spmv(A, dev[a], dev[b])
@@ -68,7 +100,7 @@ def one_case(seed):
                     pw = ctx.dot(dev[p], dev[w])
                     want = float(np.dot(model[p], model[w]))
                     if not abs(pw - want) <= 1e-12 * float(np.abs(model[p] * model[w]).sum()) + 1e-300:
-                        return "seed %d step %d %s: fused dot %r vs %r" % (seed, step, trace[-6:], pw, want)
+                        return "seed %d step %d %s: fused dot %r vs %r; %s" % (seed, step, trace[-6:], pw, want, whose(p, w))
                 got = ctx.calc_xr(dev[x], dev[r], dev[p], dev[w], alpha)
                 model[x] = model[x] + alpha * model[p]
                 model[r] = model[r] - alpha * model[w]
@@ -92,9 +124,7 @@ def one_case(seed):
                 model[w] = o.spmv(model[p])
                 want_pw = float(np.dot(model[p], model[w]))
                 if not abs(got[4] - want_pw) <= 1e-12 * float(np.abs(model[p] * model[w]).sum()) + 1e-300:
-                    # (the model's value computed a second time: a difference between the two is the checker's, not the device's)
-                    again = float(np.dot(model[p], o.spmv(model[p])))
-                    return "seed %d step %d %s: devstep p.w %r vs %r (model recomputed: %r)" % (seed, step, trace[-6:], got[4], want_pw, again)
+                    return "seed %d step %d %s: devstep p.w %r vs %r; %s" % (seed, step, trace[-6:], got[4], want_pw, whose(p, w))
                 with np.errstate(all="ignore"):
                     alpha = np.float64(cur) / np.float64(got[4])
                     model[x] = model[x] + alpha * model[p]
@@ -148,6 +178,8 @@ def main():
             print("FAIL " + msg, flush=True)
         done += 1
         seed += 1
+        if done % 5000 == 0:
+            print("... %d sequences, %d failures, %.0f s" % (done, bad, time.time() - t0), flush=True)
     print("fuzz_sequence: %d sequences, %d failures" % (done, bad), flush=True)
     return 1 if bad else 0
 
