@@ -87,7 +87,10 @@ const char *abft_hip_last_error(void);
 int abft_hip_device_count(int *count);
 
 /* Replaces `new HIPContext` (reference CGContext::create, CGContext.cpp:9-25).
- * Binds the context to `device` and creates its stream and scratch buffers. */
+ * Binds the context to `device` and creates its stream and scratch buffers.
+ * abft_hip_shutdown releases everything the context owns except its stream, which is left
+ * idle in a process-wide pool for the next abft_hip_init on that device (DESIGN.md section 5,
+ * "a context's stream is pooled": hipStreamDestroy per context corrupted the host heap). */
 int abft_hip_init(int device, abft_hip_ctx **ctx);
 int abft_hip_shutdown(abft_hip_ctx *ctx);
 
