@@ -2060,7 +2060,8 @@ static int exchange_attach_common(abft_hip_ctx *ctx, unsigned char *alias, void 
   X.timeout_ticks = (unsigned long long)((timeout_seconds > 0 ? timeout_seconds : 120.0) * 1e3 * khz);
   HIPCHK(hipMemcpyAsync(dev, &X, sizeof(X), hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));  // `X` is on the stack
-  HIPCHK(hipStreamCreateWithFlags(&ctx->xchg.side, hipStreamNonBlocking));
+  ctx->xchg.side = pooled_stream_take(ctx->device);  // (pooled like the context's own: see pooled_stream_take)
+  if (!ctx->xchg.side) return set_err(ABFT_ERR_HIP, "hipStreamCreateWithFlags failed");
   HIPCHK(hipEventCreateWithFlags(&ctx->xchg.fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ctx->xchg.join, hipEventDisableTiming));
   ctx->xchg.attached = true;
@@ -2208,7 +2209,7 @@ extern "C" int abft_hip_peer_exchange_detach(abft_hip_ctx *ctx) {
   (void)hipFree(ctx->xchg.counter);
   if (ctx->xchg.fork) (void)hipEventDestroy(ctx->xchg.fork);
   if (ctx->xchg.join) (void)hipEventDestroy(ctx->xchg.join);
-  if (ctx->xchg.side) (void)hipStreamDestroy(ctx->xchg.side);
+  if (ctx->xchg.side) pooled_stream_give_back(ctx->device, ctx->xchg.side);  // (synchronized above)
   (void)hipGetLastError();
   ctx->xchg = {};
   return ABFT_OK;
