@@ -43,6 +43,8 @@ def one_case(seed):
     ctx = amd.HIPContext(mode, "csr")
     NV = 6
     try:
+        if os.environ.get("ABFT_FUZZ_SEQ_PROFILE") == "1":  # HIP-event brackets around every kernel: events created and destroyed per context
+            ctx.profile(0xF)
         A = ctx.create_matrix(cols, rows, vals, n, len(vals))
         dev = [ctx.create_vector(n) for _ in range(NV)]
         sc = ctx.create_vector(6)  # device scalars of "devstep": {rr, -}, {rr_new, events}, {p.w, events}
